@@ -1,0 +1,53 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py, never by the product package.
+"""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+_abi = importlib.import_module("mp-mvs_amd._abi")
+
+_cache = {}
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "pm_oracle.cpp")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+def lib():
+    if "lib" not in _cache:
+        build()
+        l = C.CDLL(_LIB)
+        fns = _abi.bind(l, "orc_")
+        l.orc_create.restype = C.c_void_p
+        l.orc_create.argtypes = []
+        l.orc_num_threads.restype = C.c_int
+        l.orc_set_num_threads.argtypes = [C.c_int]
+        _cache["lib"] = l
+        _cache["fns"] = fns
+    return _cache["lib"], _cache["fns"]
+
+
+def create():
+    l, fns = lib()
+    return _abi.PatchMatchHandle(fns, l.orc_create())
+
+
+def fns():
+    return lib()[1]
+
+
+def num_threads():
+    return lib()[0].orc_num_threads()
+
+
+def set_num_threads(n):
+    lib()[0].orc_set_num_threads(int(n))
