@@ -1,0 +1,163 @@
+/* mpmvs.h -- C ABI of the MI355X-native PatchMatch hot path of MP-MVS.
+ *
+ * This is the drop-in boundary: everything below
+ * PatchMatchCUDA's host methods in the reference goes through these entry
+ * points.  The reference has no C ABI of its own; each function names the
+ * reference interface it replaces (paths relative to the reference repo).
+ * Plain pointers and sizes only; no HIP, torch or OpenCV types.
+ *
+ * Conventions
+ *   - every function returning int returns 0 on success and a negative code on
+ *     failure; mpmvs_last_error() then describes it.  Nothing here calls exit()
+ *     (the reference prints and exits, src/PatchMatch.cpp:60-65; the C++ wrapper
+ *     in mp-mvs_amd/host keeps that behaviour for drop-in use).
+ *   - a context is bound to one HIP device and one stream; distinct contexts may
+ *     be driven from distinct host threads.  Device state (planes, costs,
+ *     selected views, geometric costs) persists across mpmvs_run calls, as the
+ *     reference's does between the two Run() calls of ProcessProblem
+ *     (src/PatchMatch.cpp:522,606).
+ *   - images, depth maps, costs: row-major fp32; planes: row-major float4
+ *     (nx, ny, nz, w).  Host inputs are copied at set_* time.
+ */
+#ifndef MPMVS_H_
+#define MPMVS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* include/PatchMatch.h:35-46 (struct Camera), identical layout, 112 bytes */
+typedef struct mpmvs_camera {
+    float K[9];
+    float R[9];
+    float t[3];
+    float C[3];
+    int height;
+    int width;
+    float depth_min;
+    float depth_max;
+} mpmvs_camera;
+
+/* include/PatchMatch.h:48-67 (struct PatchMatchParams), identical layout, 56 bytes.
+ * Live fields: max_iterations, num_images, sigma_spatial, sigma_color, top_k,
+ * depth_min, depth_max, max_scale, geom_consistency, planar_prior,
+ * geomPlanarPrior.  The others are carried but unused, as in the reference. */
+typedef struct mpmvs_params {
+    int max_iterations;
+    int nSizeHalfWindow;
+    int num_images;
+    int max_image_size;
+    int nSizeStep;
+    float sigma_spatial;
+    float sigma_color;
+    int top_k;
+    float depth_min;
+    float depth_max;
+    int max_scale;
+    float scaled_cols;
+    float scaled_rows;
+    unsigned char geom_consistency;
+    unsigned char geomPlanarPrior;
+    unsigned char planar_prior;
+} mpmvs_params;
+
+typedef struct mpmvs_ctx mpmvs_ctx;
+
+#define MPMVS_MAX_SRC_VIEWS 32 /* src/PatchMatch.cu:500, width of the view bitmask */
+
+/* kernel kinds for mpmvs_step, in the launch order of PatchMatchCUDA::Run()
+ * (src/PatchMatch.cu:1188-1254) */
+enum {
+    MPMVS_KIND_INIT = 0,         /* InitializeScore   src/PatchMatch.cu:536  */
+    MPMVS_KIND_BLACK = 1,        /* BlackPixelUpdate  src/PatchMatch.cu:1000 */
+    MPMVS_KIND_RED = 2,          /* RedPixelUpdate    src/PatchMatch.cu:1011 */
+    MPMVS_KIND_DEPTH_NORMAL = 3, /* GetDepthandNormal src/PatchMatch.cu:1021 */
+    MPMVS_KIND_FILTER_BLACK = 4, /* BlackPixelFilter  src/PatchMatch.cu:1152 */
+    MPMVS_KIND_FILTER_RED = 5    /* RedPixelFilter    src/PatchMatch.cu:1164 */
+};
+
+/* number of visible HIP devices (replaces the hard-coded cudaSetDevice(0),
+ * src/PatchMatch.cpp:509) */
+int mpmvs_device_count(void);
+
+/* PatchMatchCUDA construction + AllocatePatchMatch (src/PatchMatch.cpp:516,960-976) */
+mpmvs_ctx* mpmvs_create(int device);
+/* PatchMatchCUDA::Release (src/PatchMatch.cpp:1091-1139) */
+void mpmvs_destroy(mpmvs_ctx* ctx);
+/* checkCudaCall's message (src/PatchMatch.cpp:60-65); ctx may be NULL after a
+ * failed mpmvs_create */
+const char* mpmvs_last_error(const mpmvs_ctx* ctx);
+
+/* CudaMemInit image/camera upload (src/PatchMatch.cpp:999-1025): view 0 is the
+ * reference image, 1..n-1 the sources; sizes come from cams[i].width/height;
+ * pitch_bytes[i] is the host row pitch (NULL = tightly packed). */
+int mpmvs_set_views(mpmvs_ctx* ctx, int n, const mpmvs_camera* cams, const float* const* images,
+                    const size_t* pitch_bytes);
+
+/* CudaMemInit source depth upload for geometric consistency
+ * (src/PatchMatch.cpp:1027-1050, read at :941-948); n_src == n-1 */
+int mpmvs_set_src_depths(mpmvs_ctx* ctx, int n_src, const float* const* depths, const int* widths,
+                         const int* heights, const size_t* pitch_bytes);
+/* same, from dense device buffers (pointers valid on the context's device);
+ * used by the multi-GPU pass barrier, which all-gathers depth maps in HBM */
+int mpmvs_set_src_depths_device(mpmvs_ctx* ctx, int n_src, const float* const* d_depths, const int* widths,
+                                const int* heights);
+
+/* CudaMemInit start state for geometric-consistency passes
+ * (src/PatchMatch.cpp:1073-1086): planes = (world normal, depth) float4, costs
+ * fp32; either may be NULL to leave it unchanged */
+int mpmvs_set_state(mpmvs_ctx* ctx, const void* planes4, const void* costs);
+/* selected-view bitmasks (cudaSelectedViews, include/PatchMatch.h:108); only
+ * needed to reproduce a single kernel step from a given state */
+int mpmvs_set_selected_views(mpmvs_ctx* ctx, const void* sel_u32);
+/* CudaPlanarPriorInitialization (src/PatchMatch.cpp:978-996): per-pixel prior
+ * plane (n, d) in the reference-camera frame and mask (>0 = has prior) */
+int mpmvs_set_prior(mpmvs_ctx* ctx, const void* prior_planes4, const void* mask_u32);
+
+/* PatchMatchCUDA::Run() (src/PatchMatch.cu:1188-1254) without its final
+ * device-to-host copies: InitializeScore, the red/black schedule selected by
+ * params, GetDepthandNormal, both filters.  `seed` replaces
+ * curand_init(clock64(), ...) (src/PatchMatch.cu:546).  Blocks until done. */
+int mpmvs_run(mpmvs_ctx* ctx, const mpmvs_params* params, uint64_t seed);
+/* one kernel of Run(), for parity tests; launch_id selects the RNG stream the
+ * way Run() numbers its launches (0 = InitializeScore, then in launch order) */
+int mpmvs_step(mpmvs_ctx* ctx, const mpmvs_params* params, uint64_t seed, int kind, int iter, int scale,
+               uint32_t launch_id);
+
+/* the cudaMemcpy device-to-host block of Run() (src/PatchMatch.cu:1246-1251);
+ * any pointer may be NULL */
+int mpmvs_get(mpmvs_ctx* ctx, void* planes4, void* costs, void* geom_costs);
+int mpmvs_get_selected_views(mpmvs_ctx* ctx, void* sel_u32);
+/* dense fp32 depth map (plane .w) written to a device buffer of H*W floats; the
+ * multi-GPU barrier all-gathers these (replaces the depths.dmb round trip,
+ * src/PatchMatch.cpp:620-633 -> :941-948) */
+int mpmvs_export_depth_device(mpmvs_ctx* ctx, float* d_out);
+
+/* ---- probes used by the parity tests ------------------------------------ */
+/* ComputeBilateralNCC (src/PatchMatch.cu:325-414) of per-pixel camera-frame
+ * planes against every source view; out is [num_images-1][H][W] */
+int mpmvs_eval_ncc(mpmvs_ctx* ctx, const mpmvs_params* params, const void* planes_cam4, int scale, void* out);
+/* ComputeGeomConsistencyCost (src/PatchMatch.cu:617-640); out [num_images-1][H][W] */
+int mpmvs_eval_geom(mpmvs_ctx* ctx, const mpmvs_params* params, const void* planes_cam4, void* out);
+/* ComputeHomography (src/PatchMatch.cu:228-279) for one plane and source view
+ * (0-based); H9 receives 9 floats, row-major */
+int mpmvs_homography(mpmvs_ctx* ctx, const void* plane4, int src_view, void* H9);
+/* canonical device math, fn: 0 rcp, 1 exp, 2 sin, 3 cos, 4 acos */
+int mpmvs_math(int fn, const void* in, void* out, int n);
+/* first n uniforms of RNG stream (seed, pixel, launch_id) */
+int mpmvs_rng(uint64_t seed, uint32_t pix, uint32_t launch_id, int n, void* out);
+
+/* ---- measurement --------------------------------------------------------- */
+/* HIP-event timing of the launches of the last mpmvs_run, on the context's
+ * stream: ms[k] / count[k] per kernel kind (6 entries each). Profiling is off
+ * by default (events add a little host work per launch). */
+int mpmvs_set_profiling(mpmvs_ctx* ctx, int enable);
+int mpmvs_get_kernel_times(mpmvs_ctx* ctx, float* ms6, int* count6);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPMVS_H_ */

@@ -1,0 +1,626 @@
+// mpmvs_api.hip -- host side of the C ABI declared in include/mpmvs.h: context
+// and HBM residency management, uploads, the Run() launch schedule
+// (reference src/PatchMatch.cu:1188-1254) and the probes used by the parity tests.
+//
+// HBM layout per context:
+//   reference image   (W+40) x (H+40) fp32, replicated apron 20  (window radius <= 20)
+//   source images     (w+2)  x (h+2)  fp32, replicated apron 1   (bilinear clamp for free)
+//   source depth maps dense w x h fp32 (geometric consistency only)
+//   planes float4, costs f32, selected views u32, geometric costs f32 [H*W]
+//   prior planes float4 + mask u32 [H*W] (planar prior only)
+//   ProblemDev: cameras + per-view constants, read through the scalar cache
+// There is no per-pixel RNG state (the reference keeps 48 B/pixel of cuRAND).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mpmvs.h"
+#include "pm_kernels.hpp"
+
+using namespace pm;
+
+static_assert(sizeof(mpmvs_camera) == 112, "Camera layout");
+static_assert(sizeof(mpmvs_params) == 56, "PatchMatchParams layout");
+
+struct mpmvs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n_img = 0, W = 0, H = 0;
+    std::vector<mpmvs_camera> cams;
+    ProblemDev hP;               // host mirror
+    ProblemDev* dP = nullptr;    // device copy
+    float* d_ref = nullptr;
+    std::vector<float*> d_src;   // padded source images
+    std::vector<float*> d_depth; // dense source depth maps
+    StateDev S{};
+    float4* d_prior = nullptr;
+    uint32_t* d_mask = nullptr;
+    bool have_prior = false, have_depths = false;
+    bool profiling = false;
+    float k_ms[6] = {0, 0, 0, 0, 0, 0};
+    int k_cnt[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;  // (kind, (start, stop))
+    std::vector<hipEvent_t> event_pool;
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+#define HIPCHK(ctx, expr)                                                                           \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                         \
+            return -100;                                                                            \
+        }                                                                                           \
+    } while (0)
+
+static int fail(mpmvs_ctx* c, int code, const char* msg) {
+    c->err = msg;
+    return code;
+}
+
+static void free_views(mpmvs_ctx* c) {
+    if (c->d_ref) (void)hipFree(c->d_ref);
+    c->d_ref = nullptr;
+    for (float* p : c->d_src) (void)hipFree(p);
+    c->d_src.clear();
+    for (float* p : c->d_depth) (void)hipFree(p);
+    c->d_depth.clear();
+    if (c->S.planes) (void)hipFree(c->S.planes);
+    if (c->S.costs) (void)hipFree(c->S.costs);
+    if (c->S.sel) (void)hipFree(c->S.sel);
+    if (c->S.geom) (void)hipFree(c->S.geom);
+    if (c->d_prior) (void)hipFree(c->d_prior);
+    if (c->d_mask) (void)hipFree(c->d_mask);
+    c->S = StateDev{};
+    c->d_prior = nullptr;
+    c->d_mask = nullptr;
+    c->have_prior = c->have_depths = false;
+}
+
+static void cam_to_dev(const mpmvs_camera& s, CamDev& d) {
+    std::memcpy(d.K, s.K, sizeof(d.K));
+    std::memcpy(d.R, s.R, sizeof(d.R));
+    std::memcpy(d.t, s.t, sizeof(d.t));
+    std::memcpy(d.C, s.C, sizeof(d.C));
+}
+
+// per-view constants of H = A - b m^T, evaluated in double in the fixed order
+// of DESIGN.md section 3.3 and rounded once to fp32
+static void precompute_views(mpmvs_ctx* c) {
+    const mpmvs_camera& r = c->cams[0];
+    ProblemDev& P = c->hP;
+    cam_to_dev(r, P.cam);
+    const double fx = r.K[0], fy = r.K[4], cx = r.K[2], cy = r.K[5];
+    P.ifx = (float)(1.0 / fx);
+    P.ify = (float)(1.0 / fy);
+    P.cxfx = (float)(cx / fx);
+    P.cyfy = (float)(cy / fy);
+    P.fxfy = r.K[0] / r.K[4];
+    P.W = r.width;
+    P.H = r.height;
+    P.V = c->n_img - 1;
+    for (int v = 1; v < c->n_img; ++v) {
+        const mpmvs_camera& s = c->cams[v];
+        ViewDev& o = P.views[v - 1];
+        double Rrel[9], Crel[3], trel[3], M[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                Rrel[i * 3 + j] = ((double)s.R[i * 3] * (double)r.R[j * 3] + (double)s.R[i * 3 + 1] * (double)r.R[j * 3 + 1]) +
+                                  (double)s.R[i * 3 + 2] * (double)r.R[j * 3 + 2];
+        for (int k = 0; k < 3; ++k) Crel[k] = (double)r.C[k] - (double)s.C[k];
+        for (int i = 0; i < 3; ++i)
+            trel[i] = ((double)s.R[i * 3] * Crel[0] + (double)s.R[i * 3 + 1] * Crel[1]) + (double)s.R[i * 3 + 2] * Crel[2];
+        for (int i = 0; i < 3; ++i) {
+            M[i * 3 + 0] = Rrel[i * 3 + 0] / fx;
+            M[i * 3 + 1] = Rrel[i * 3 + 1] / fy;
+            M[i * 3 + 2] = (Rrel[i * 3 + 2] - (Rrel[i * 3 + 0] * cx) / fx) - (Rrel[i * 3 + 1] * cy) / fy;
+        }
+        const double k0 = s.K[0], k2 = s.K[2], k4 = s.K[4], k5 = s.K[5], k8 = s.K[8];
+        for (int j = 0; j < 3; ++j) {
+            o.A[0 + j] = (float)(k0 * M[0 + j] + k2 * M[6 + j]);
+            o.A[3 + j] = (float)(k4 * M[3 + j] + k5 * M[6 + j]);
+            o.A[6 + j] = (float)(k8 * M[6 + j]);
+        }
+        o.b[0] = (float)(k0 * trel[0] + k2 * trel[2]);
+        o.b[1] = (float)(k4 * trel[1] + k5 * trel[2]);
+        o.b[2] = (float)(k8 * trel[2]);
+        o.w = s.width;
+        o.h = s.height;
+        o.wf = (float)s.width;
+        o.hf = (float)s.height;
+        o.wm1 = (float)(s.width - 1);
+        o.hm1 = (float)(s.height - 1);
+        cam_to_dev(s, o.cam);
+    }
+}
+
+static int upload_problem(mpmvs_ctx* c) {
+    HIPCHK(c, hipMemcpyAsync(c->dP, &c->hP, sizeof(ProblemDev), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// host image -> dense staging buffer -> replicate-padded resident image
+static int upload_padded(mpmvs_ctx* c, const float* host, size_t pitch, int w, int h, int apron, float** out) {
+    float* d_raw = nullptr;
+    HIPCHK(c, hipMalloc(&d_raw, (size_t)w * h * 4));
+    HIPCHK(c, hipMemcpy2DAsync(d_raw, (size_t)w * 4, host, pitch, (size_t)w * 4, h, hipMemcpyHostToDevice, c->stream));
+    const int pw = w + 2 * apron, ph = h + 2 * apron;
+    float* d_pad = nullptr;
+    HIPCHK(c, hipMalloc(&d_pad, (size_t)pw * ph * 4));
+    hipLaunchKernelGGL(k_pad, dim3((pw + 255) / 256, ph), dim3(256), 0, c->stream, d_raw, w, h, d_pad, apron);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(d_raw));
+    *out = d_pad;
+    return 0;
+}
+
+extern "C" {
+
+int mpmvs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+mpmvs_ctx* mpmvs_create(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_err = std::string("no HIP device available: ") + hipGetErrorString(e);
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        g_create_err = "device index out of range";
+        return nullptr;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return nullptr;
+    }
+    mpmvs_ctx* c = new mpmvs_ctx();
+    c->device = device;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipMalloc(&c->dP, sizeof(ProblemDev))) != hipSuccess) {
+        g_create_err = std::string("context setup: ") + hipGetErrorString(e);
+        delete c;
+        return nullptr;
+    }
+    std::memset(&c->hP, 0, sizeof(ProblemDev));
+    return c;
+}
+
+void mpmvs_destroy(mpmvs_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_views(c);
+    for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
+    if (c->dP) (void)hipFree(c->dP);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* mpmvs_last_error(const mpmvs_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int mpmvs_set_views(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* const* images, const size_t* pitch_bytes) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n < 2 || n - 1 > MPMVS_MAX_SRC_VIEWS) return fail(c, -1, "need 2..33 views");
+    for (int i = 0; i < n; ++i)
+        if (cams[i].width <= 0 || cams[i].height <= 0 || !images[i]) return fail(c, -2, "bad image size or null image");
+    free_views(c);
+    c->n_img = n;
+    c->cams.assign(cams, cams + n);
+    c->W = cams[0].width;
+    c->H = cams[0].height;
+    std::memset(&c->hP, 0, sizeof(ProblemDev));
+    precompute_views(c);
+    int rc;
+    {
+        const size_t pitch = pitch_bytes ? pitch_bytes[0] : (size_t)c->W * 4;
+        if ((rc = upload_padded(c, images[0], pitch, c->W, c->H, kRefApron, &c->d_ref))) return rc;
+        c->hP.ref_pitch = c->W + 2 * kRefApron;
+        c->hP.ref_img = c->d_ref + (size_t)kRefApron * c->hP.ref_pitch + kRefApron;
+    }
+    c->d_src.assign(n - 1, nullptr);
+    for (int v = 1; v < n; ++v) {
+        const int w = cams[v].width, h = cams[v].height;
+        const size_t pitch = pitch_bytes ? pitch_bytes[v] : (size_t)w * 4;
+        if ((rc = upload_padded(c, images[v], pitch, w, h, kSrcApron, &c->d_src[v - 1]))) return rc;
+        ViewDev& o = c->hP.views[v - 1];
+        o.pitch = w + 2 * kSrcApron;
+        o.img = c->d_src[v - 1] + (size_t)kSrcApron * o.pitch + kSrcApron;
+    }
+    const size_t wh = (size_t)c->W * c->H;
+    HIPCHK(c, hipMalloc(&c->S.planes, wh * 16));
+    HIPCHK(c, hipMalloc(&c->S.costs, wh * 4));
+    HIPCHK(c, hipMalloc(&c->S.sel, wh * 4));
+    HIPCHK(c, hipMalloc(&c->S.geom, wh * 4));
+    HIPCHK(c, hipMemsetAsync(c->S.planes, 0, wh * 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->S.costs, 0, wh * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->S.sel, 0, wh * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->S.geom, 0, wh * 4, c->stream));
+    return upload_problem(c);
+}
+
+static int attach_depths(mpmvs_ctx* c, int n_src, const int* widths, const int* heights) {
+    for (int i = 0; i < n_src; ++i) {
+        ViewDev& o = c->hP.views[i];
+        o.depth = c->d_depth[i];
+        o.dw = widths[i];
+        o.dh = heights[i];
+        o.dwm1 = (float)(widths[i] - 1);
+        o.dhm1 = (float)(heights[i] - 1);
+    }
+    c->have_depths = true;
+    return upload_problem(c);
+}
+
+int mpmvs_set_src_depths(mpmvs_ctx* c, int n_src, const float* const* depths, const int* widths, const int* heights, const size_t* pitch_bytes) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n_img < 2 || n_src != c->n_img - 1) return fail(c, -1, "n_src must equal the number of source views");
+    for (float* p : c->d_depth) (void)hipFree(p);
+    c->d_depth.assign(n_src, nullptr);
+    for (int i = 0; i < n_src; ++i) {
+        if (widths[i] <= 0 || heights[i] <= 0 || !depths[i]) return fail(c, -2, "bad depth map");
+        HIPCHK(c, hipMalloc(&c->d_depth[i], (size_t)widths[i] * heights[i] * 4));
+        const size_t pitch = pitch_bytes ? pitch_bytes[i] : (size_t)widths[i] * 4;
+        HIPCHK(c, hipMemcpy2DAsync(c->d_depth[i], (size_t)widths[i] * 4, depths[i], pitch, (size_t)widths[i] * 4, heights[i], hipMemcpyHostToDevice, c->stream));
+    }
+    return attach_depths(c, n_src, widths, heights);
+}
+
+int mpmvs_set_src_depths_device(mpmvs_ctx* c, int n_src, const float* const* d_depths, const int* widths, const int* heights) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n_img < 2 || n_src != c->n_img - 1) return fail(c, -1, "n_src must equal the number of source views");
+    for (float* p : c->d_depth) (void)hipFree(p);
+    c->d_depth.assign(n_src, nullptr);
+    for (int i = 0; i < n_src; ++i) {
+        if (widths[i] <= 0 || heights[i] <= 0 || !d_depths[i]) return fail(c, -2, "bad depth map");
+        const size_t bytes = (size_t)widths[i] * heights[i] * 4;
+        HIPCHK(c, hipMalloc(&c->d_depth[i], bytes));
+        HIPCHK(c, hipMemcpyAsync(c->d_depth[i], d_depths[i], bytes, hipMemcpyDeviceToDevice, c->stream));
+    }
+    return attach_depths(c, n_src, widths, heights);
+}
+
+int mpmvs_set_state(mpmvs_ctx* c, const void* planes4, const void* costs) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->S.planes) return fail(c, -1, "set_views first");
+    const size_t wh = (size_t)c->W * c->H;
+    if (planes4) HIPCHK(c, hipMemcpyAsync(c->S.planes, planes4, wh * 16, hipMemcpyHostToDevice, c->stream));
+    if (costs) HIPCHK(c, hipMemcpyAsync(c->S.costs, costs, wh * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int mpmvs_set_selected_views(mpmvs_ctx* c, const void* sel) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->S.sel) return fail(c, -1, "set_views first");
+    HIPCHK(c, hipMemcpyAsync(c->S.sel, sel, (size_t)c->W * c->H * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int mpmvs_set_prior(mpmvs_ctx* c, const void* prior4, const void* mask) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->S.planes) return fail(c, -1, "set_views first");
+    const size_t wh = (size_t)c->W * c->H;
+    if (!c->d_prior) HIPCHK(c, hipMalloc(&c->d_prior, wh * 16));
+    if (!c->d_mask) HIPCHK(c, hipMalloc(&c->d_mask, wh * 4));
+    HIPCHK(c, hipMemcpyAsync(c->d_prior, prior4, wh * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_mask, mask, wh * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->S.prior = c->d_prior;
+    c->S.mask = c->d_mask;
+    c->have_prior = true;
+    return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------
+static int check_ready(mpmvs_ctx* c, const mpmvs_params* p) {
+    if (c->n_img < 2) return fail(c, -1, "set_views not called (need >= 2 views)");
+    if (p->num_images != c->n_img) return fail(c, -2, "params.num_images != number of views");
+    if (p->max_scale < 0 || p->max_scale > 2) return fail(c, -3, "max_scale must be 0..2 (window radius <= 20)");
+    if (p->geom_consistency && !c->have_depths) return fail(c, -4, "geom_consistency needs source depth maps");
+    if (p->planar_prior && !c->have_prior) return fail(c, -5, "planar_prior needs set_prior");
+    return 0;
+}
+
+static hipEvent_t get_event(mpmvs_ctx* c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+template <bool GEOM, bool PRIOR>
+static void launch_update(mpmvs_ctx* c, dim3 grid, const LaunchArgs& a) {
+    if (c->hP.V <= 8)
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 8>), grid, dim3(256), 0, c->stream, c->dP, c->S, a);
+    else
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, kMaxViews>), grid, dim3(256), 0, c->stream, c->dP, c->S, a);
+}
+
+static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int kind, int iter, int scale, uint32_t launch) {
+    if (scale < 0 || scale > 2) return fail(c, -3, "scale must be 0..2");
+    LaunchArgs a;
+    a.seed = seed;
+    a.launch = launch;
+    a.iter = iter;
+    a.scale = scale;
+    a.parity = (kind == MPMVS_KIND_RED || kind == MPMVS_KIND_FILTER_RED) ? 1 : 0;
+    a.ylimit = 2 * 16 * (((c->H / 2) + 15) / 16);  // ref .cu:1196
+    a.top_k = p->top_k;
+    a.depth_min = p->depth_min;
+    a.depth_max = p->depth_max;
+    a.two_ss = (2.0f * p->sigma_spatial) * p->sigma_spatial;
+    a.two_sc = (2.0f * p->sigma_color) * p->sigma_color;
+    a.init_random = (!p->geom_consistency && !p->planar_prior) ? 1 : 0;
+    a.use_prior = p->planar_prior ? 1 : 0;
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profiling) {
+        e0 = get_event(c);
+        e1 = get_event(c);
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+    }
+    const dim3 blk(256);
+    const dim3 grid_dense((c->W + 15) / 16, (c->H + 15) / 16);
+    const int rows = c->H < a.ylimit ? c->H : a.ylimit;
+    const dim3 grid_chk((c->W + 31) / 32, (rows + 15) / 16);
+    switch (kind) {
+        case MPMVS_KIND_INIT:
+            if (c->hP.V <= 8)
+                hipLaunchKernelGGL((k_init<8>), grid_dense, blk, 0, c->stream, c->dP, c->S, a);
+            else
+                hipLaunchKernelGGL((k_init<kMaxViews>), grid_dense, blk, 0, c->stream, c->dP, c->S, a);
+            break;
+        case MPMVS_KIND_BLACK:
+        case MPMVS_KIND_RED:
+            if (p->geom_consistency && p->planar_prior)
+                launch_update<true, true>(c, grid_chk, a);
+            else if (p->geom_consistency)
+                launch_update<true, false>(c, grid_chk, a);
+            else if (p->planar_prior)
+                launch_update<false, true>(c, grid_chk, a);
+            else
+                launch_update<false, false>(c, grid_chk, a);
+            break;
+        case MPMVS_KIND_DEPTH_NORMAL:
+            hipLaunchKernelGGL(k_depth_normal, grid_dense, blk, 0, c->stream, c->dP, c->S);
+            break;
+        case MPMVS_KIND_FILTER_BLACK:
+        case MPMVS_KIND_FILTER_RED:
+            hipLaunchKernelGGL(k_filter, grid_chk, blk, 0, c->stream, c->dP, c->S, a);
+            break;
+        default:
+            return fail(c, -6, "bad kernel kind");
+    }
+    HIPCHK(c, hipGetLastError());
+    if (c->profiling) {
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        c->pending.push_back({kind, {e0, e1}});
+    }
+    return 0;
+}
+
+static int finish(mpmvs_ctx* c) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto& pe : c->pending) {
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, pe.second.first, pe.second.second);
+        c->k_ms[pe.first] += ms;
+        c->k_cnt[pe.first] += 1;
+        c->event_pool.push_back(pe.second.first);
+        c->event_pool.push_back(pe.second.second);
+    }
+    c->pending.clear();
+    return 0;
+}
+
+extern "C" {
+
+int mpmvs_run(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed) {
+    if (!c || !p) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = check_ready(c, p);
+    if (rc) return rc;
+    for (int k = 0; k < 6; ++k) {
+        c->k_ms[k] = 0.0f;
+        c->k_cnt[k] = 0;
+    }
+    uint32_t launch = 0;
+    if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_INIT, 0, p->max_scale, launch++))) return rc;
+    if (p->geom_consistency || p->planar_prior) {
+        for (int i = 0; i < p->max_iterations; ++i) {
+            if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_BLACK, i, 0, launch++))) return rc;
+            if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_RED, i, 0, launch++))) return rc;
+        }
+    } else {
+        for (int s = p->max_scale; s >= 0; --s)
+            for (int i = 0; i < p->max_iterations; ++i) {
+                if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_BLACK, i, s, launch++))) return rc;
+                if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_RED, i, s, launch++))) return rc;
+            }
+    }
+    if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_DEPTH_NORMAL, 0, 0, launch++))) return rc;
+    if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_FILTER_BLACK, 0, 0, launch++))) return rc;
+    if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_FILTER_RED, 0, 0, launch++))) return rc;
+    return finish(c);
+}
+
+int mpmvs_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int kind, int iter, int scale, uint32_t launch_id) {
+    if (!c || !p) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = check_ready(c, p);
+    if (rc) return rc;
+    if ((rc = enqueue_step(c, p, seed, kind, iter, scale, launch_id))) return rc;
+    return finish(c);
+}
+
+int mpmvs_get(mpmvs_ctx* c, void* planes4, void* costs, void* geom) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->S.planes) return fail(c, -1, "set_views first");
+    const size_t wh = (size_t)c->W * c->H;
+    if (planes4) HIPCHK(c, hipMemcpyAsync(planes4, c->S.planes, wh * 16, hipMemcpyDeviceToHost, c->stream));
+    if (costs) HIPCHK(c, hipMemcpyAsync(costs, c->S.costs, wh * 4, hipMemcpyDeviceToHost, c->stream));
+    if (geom) HIPCHK(c, hipMemcpyAsync(geom, c->S.geom, wh * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int mpmvs_get_selected_views(mpmvs_ctx* c, void* sel) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->S.sel) return fail(c, -1, "set_views first");
+    HIPCHK(c, hipMemcpyAsync(sel, c->S.sel, (size_t)c->W * c->H * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int mpmvs_export_depth_device(mpmvs_ctx* c, float* d_out) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->S.planes) return fail(c, -1, "set_views first");
+    const int n = c->W * c->H;
+    hipLaunchKernelGGL(k_export_depth, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S.planes, d_out, n);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int mpmvs_eval_ncc(mpmvs_ctx* c, const mpmvs_params* p, const void* planes_cam4, int scale, void* out) {
+    if (!c || !p) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = check_ready(c, p);
+    if (rc) return rc;
+    if (scale < 0 || scale > 2) return fail(c, -3, "scale must be 0..2");
+    const size_t wh = (size_t)c->W * c->H;
+    const int V = c->hP.V;
+    float4* d_pl = nullptr;
+    float* d_out = nullptr;
+    HIPCHK(c, hipMalloc(&d_pl, wh * 16));
+    HIPCHK(c, hipMalloc(&d_out, wh * 4 * V));
+    HIPCHK(c, hipMemcpyAsync(d_pl, planes_cam4, wh * 16, hipMemcpyHostToDevice, c->stream));
+    LaunchArgs a{};
+    a.scale = scale;
+    a.two_ss = (2.0f * p->sigma_spatial) * p->sigma_spatial;
+    a.two_sc = (2.0f * p->sigma_color) * p->sigma_color;
+    const dim3 grid((c->W + 15) / 16, (c->H + 15) / 16);
+    if (V <= 8)
+        hipLaunchKernelGGL((k_eval_ncc<8>), grid, dim3(256), 0, c->stream, c->dP, d_pl, d_out, a);
+    else
+        hipLaunchKernelGGL((k_eval_ncc<kMaxViews>), grid, dim3(256), 0, c->stream, c->dP, d_pl, d_out, a);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, d_out, wh * 4 * V, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(d_pl));
+    HIPCHK(c, hipFree(d_out));
+    return 0;
+}
+
+int mpmvs_eval_geom(mpmvs_ctx* c, const mpmvs_params* p, const void* planes_cam4, void* out) {
+    if (!c || !p) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n_img < 2) return fail(c, -1, "set_views first");
+    if (!c->have_depths) return fail(c, -4, "need source depth maps");
+    const size_t wh = (size_t)c->W * c->H;
+    const int V = c->hP.V;
+    float4* d_pl = nullptr;
+    float* d_out = nullptr;
+    HIPCHK(c, hipMalloc(&d_pl, wh * 16));
+    HIPCHK(c, hipMalloc(&d_out, wh * 4 * V));
+    HIPCHK(c, hipMemcpyAsync(d_pl, planes_cam4, wh * 16, hipMemcpyHostToDevice, c->stream));
+    const dim3 grid((c->W + 15) / 16, (c->H + 15) / 16);
+    hipLaunchKernelGGL(k_eval_geom, grid, dim3(256), 0, c->stream, c->dP, d_pl, d_out);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, d_out, wh * 4 * V, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(d_pl));
+    HIPCHK(c, hipFree(d_out));
+    return 0;
+}
+
+int mpmvs_homography(mpmvs_ctx* c, const void* plane4, int v, void* H9) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n_img < 2 || v < 0 || v >= c->hP.V) return fail(c, -1, "bad source view");
+    float* d_h = nullptr;
+    HIPCHK(c, hipMalloc(&d_h, 9 * 4));
+    const float* pf = (const float*)plane4;
+    hipLaunchKernelGGL(k_homography, dim3(1), dim3(64), 0, c->stream, c->dP, make_float4(pf[0], pf[1], pf[2], pf[3]), v, d_h);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(H9, d_h, 9 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(d_h));
+    return 0;
+}
+
+int mpmvs_math(int fn, const void* in, void* out, int n) {
+    if (fn < 0 || fn > 4 || n <= 0) return -1;
+    float *d_in = nullptr, *d_out = nullptr;
+    if (hipMalloc(&d_in, (size_t)n * 4) != hipSuccess) return -100;
+    if (hipMalloc(&d_out, (size_t)n * 4) != hipSuccess) return -100;
+    int rc = 0;
+    if (hipMemcpy(d_in, in, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) rc = -100;
+    if (!rc) {
+        hipLaunchKernelGGL(k_math, dim3((n + 255) / 256), dim3(256), 0, nullptr, fn, d_in, d_out, n);
+        if (hipGetLastError() != hipSuccess) rc = -100;
+    }
+    if (!rc && hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = -100;
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+int mpmvs_rng(uint64_t seed, uint32_t pix, uint32_t launch_id, int n, void* out) {
+    if (n <= 0) return -1;
+    float* d_out = nullptr;
+    if (hipMalloc(&d_out, (size_t)n * 4) != hipSuccess) return -100;
+    int rc = 0;
+    hipLaunchKernelGGL(k_rng, dim3(1), dim3(64), 0, nullptr, seed, pix, launch_id, n, d_out);
+    if (hipGetLastError() != hipSuccess) rc = -100;
+    if (!rc && hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = -100;
+    (void)hipFree(d_out);
+    return rc;
+}
+
+int mpmvs_set_profiling(mpmvs_ctx* c, int enable) {
+    if (!c) return -1;
+    c->profiling = enable != 0;
+    return 0;
+}
+
+int mpmvs_get_kernel_times(mpmvs_ctx* c, float* ms6, int* count6) {
+    if (!c) return -1;
+    for (int k = 0; k < 6; ++k) {
+        if (ms6) ms6[k] = c->k_ms[k];
+        if (count6) count6[k] = c->k_cnt[k];
+    }
+    return 0;
+}
+
+}  // extern "C"

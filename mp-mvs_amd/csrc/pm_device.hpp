@@ -1,0 +1,430 @@
+// pm_device.hpp -- device-side building blocks of the PatchMatch hot path for
+// gfx950 (MI355X): canonical deterministic fp32 math, Philox RNG, software
+// bilinear "texture" fetch (CDNA has no sampler hardware), homography warp,
+// bilateral NCC, geometric-consistency cost.
+//
+// Arithmetic follows DESIGN.md section 3 ("canonical arithmetic"): every fp32
+// operation is a correctly rounded IEEE operation or an explicit fma, so this
+// file must be compiled with -ffp-contract=off and without fast-math.  The
+// reference functions each block restates are cited as "ref .cu:LINES"
+// (reference src/PatchMatch.cu).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pm {
+
+#define PM_DEV __device__ __forceinline__
+
+constexpr int kMaxViews = 32;   // ref .cu:500 and the u32 view mask
+constexpr int kRefApron = 20;   // widest NCC window radius (scale 2): ref .cu:342-346
+constexpr int kSrcApron = 1;    // replicated border that makes clamp addressing free
+
+// ---------------------------------------------------------------------------
+// device-resident problem description (uniform across a launch -> scalar loads)
+// ---------------------------------------------------------------------------
+struct CamDev {
+    float K[9];
+    float R[9];
+    float t[3];
+    float C[3];
+};
+
+struct ViewDev {
+    float A[9];        // K_s R_rel K_r^-1          (H = A - b m^T)
+    float b[3];        // K_s t_rel
+    float wf, hf;      // (float)width, (float)height
+    float wm1, hm1;    // (float)(width-1), (float)(height-1)
+    const float* img;  // texel (0,0) of the apron-padded source image
+    int pitch;         // floats per padded row
+    int w, h;
+    const float* depth;  // dense source depth map (geometric consistency) or null
+    int dw, dh;
+    float dwm1, dhm1;
+    CamDev cam;
+};
+
+struct ProblemDev {
+    CamDev cam;          // reference camera
+    float ifx, ify;      // 1/fx, 1/fy        (rounded from double)
+    float cxfx, cyfy;    // cx/fx, cy/fy      (rounded from double)
+    float fxfy;          // K[0] / K[4]       (fp32 division, as ref .cu:86 does per call)
+    int W, H, V;
+    const float* ref_img;  // texel (0,0) of the reference image, apron kRefApron
+    int ref_pitch;
+    ViewDev views[kMaxViews];
+};
+
+struct StateDev {
+    float4* planes;
+    float* costs;
+    uint32_t* sel;
+    float* geom;
+    const float4* prior;
+    const uint32_t* mask;
+};
+
+// ---------------------------------------------------------------------------
+// canonical math
+// ---------------------------------------------------------------------------
+PM_DEV float d_rcp(float z) {
+    const uint32_t zi = __float_as_uint(z);
+    const uint32_t ai = zi & 0x7fffffffu;
+    const float az = __uint_as_float(ai);
+    float r = __uint_as_float(0x7EF311C7u - ai);
+    r = __builtin_fmaf(r, __builtin_fmaf(-az, r, 1.0f), r);
+    r = __builtin_fmaf(r, __builtin_fmaf(-az, r, 1.0f), r);
+    r = __builtin_fmaf(r, __builtin_fmaf(-az, r, 1.0f), r);
+    return __uint_as_float(__float_as_uint(r) | (zi & 0x80000000u));
+}
+
+PM_DEV float d_exp(float x) {
+    if (x < -80.0f) return 0.0f;
+    if (x > 80.0f) return __uint_as_float(0x7f800000u);
+    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    const float y = __builtin_fmaf(p, r * r, r) + 1.0f;
+    if (!(x == x)) return y;
+    const int ni = (int)n;
+    return __uint_as_float(__float_as_uint(y) + ((uint32_t)ni << 23));
+}
+
+PM_DEV float d_sin(float a) {
+    const float z = a * a;
+    float p = -1.9515295891e-4f;
+    p = __builtin_fmaf(p, z, 8.3321608736e-3f);
+    p = __builtin_fmaf(p, z, -1.6666654611e-1f);
+    return __builtin_fmaf(p * z, a, a);
+}
+
+PM_DEV float d_cos(float a) {
+    const float z = a * a;
+    float p = 2.443315711809948e-5f;
+    p = __builtin_fmaf(p, z, -1.388731625493765e-3f);
+    p = __builtin_fmaf(p, z, 4.166664568298827e-2f);
+    return __builtin_fmaf(p * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+}
+
+PM_DEV float d_asin_core(float x) {
+    const float z = x * x;
+    float p = 4.2163199048e-2f;
+    p = __builtin_fmaf(p, z, 2.4181311049e-2f);
+    p = __builtin_fmaf(p, z, 4.5470025998e-2f);
+    p = __builtin_fmaf(p, z, 7.4953002686e-2f);
+    p = __builtin_fmaf(p, z, 1.6666752422e-1f);
+    return __builtin_fmaf(p * z, x, x);
+}
+
+PM_DEV float d_acos(float x) {
+    if (!(x >= -1.0f && x <= 1.0f)) return __uint_as_float(0x7fc00000u);
+    if (x > 0.5f) return 2.0f * d_asin_core(__builtin_sqrtf(0.5f * (1.0f - x)));
+    if (x < -0.5f) return 3.14159265358979323846f - 2.0f * d_asin_core(__builtin_sqrtf(0.5f * (1.0f + x)));
+    return 1.57079632679489661923f - d_asin_core(x);
+}
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10, counter = (pixel, launch, block, tag); replaces the 48-byte
+// per-pixel cuRAND XORWOW state (ref .cu:546, include/PatchMatch.h:107): the
+// stream position lives in a register, nothing is stored per pixel.
+// ---------------------------------------------------------------------------
+struct Rng {
+    uint32_t key0, key1, pix, launch, k;
+    uint32_t b0, b1, b2, b3;
+};
+
+PM_DEV void philox_refill(Rng& g) {
+    uint32_t c0 = g.pix, c1 = g.launch, c2 = g.k >> 2, c3 = 0x4D504D56u;
+    uint32_t k0 = g.key0, k1 = g.key1;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0;
+        const uint32_t n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    g.b0 = c0; g.b1 = c1; g.b2 = c2; g.b3 = c3;
+}
+
+PM_DEV Rng rng_make(uint64_t seed, uint32_t pix, uint32_t launch) {
+    Rng g;
+    g.key0 = (uint32_t)seed;
+    g.key1 = (uint32_t)(seed >> 32);
+    g.pix = pix;
+    g.launch = launch;
+    g.k = 0;
+    g.b0 = g.b1 = g.b2 = g.b3 = 0;
+    return g;
+}
+
+// uniform in (0, 1]: ((x >> 8) + 1) * 2^-24
+PM_DEV float rng_uniform(Rng& g) {
+    const uint32_t lane = g.k & 3u;
+    if (lane == 0u) philox_refill(g);
+    const uint32_t x = lane == 0u ? g.b0 : (lane == 1u ? g.b1 : (lane == 2u ? g.b2 : g.b3));
+    g.k++;
+    return (float)((x >> 8) + 1u) * 5.9604644775390625e-8f;
+}
+
+// ---------------------------------------------------------------------------
+// geometry helpers
+// ---------------------------------------------------------------------------
+// ref .cu:84-87
+PM_DEV float depth_from_plane(const ProblemDev& P, const float4 pl, int px, int py) {
+    const float den = ((float)px - P.cam.K[2]) * pl.x + (P.fxfy * ((float)py - P.cam.K[5])) * pl.y + P.cam.K[0] * pl.z;
+    return (-pl.w * P.cam.K[0]) / den;
+}
+// same for an arbitrary camera (geometric consistency needs only the reference one)
+// ref .cu:163-176
+PM_DEV float plane_offset(const ProblemDev& P, int px, int py, float depth, const float4 n) {
+    const float X0 = (depth * ((float)px - P.cam.K[2])) / P.cam.K[0];
+    const float X1 = (depth * ((float)py - P.cam.K[5])) / P.cam.K[4];
+    return -((n.x * X0 + n.y * X1) + n.z * depth);
+}
+// ref .cu:188-195
+PM_DEV void normalize3(float4& n) {
+    const float ns = (n.x * n.x + n.y * n.y) + n.z * n.z;
+    const float inv = 1.0f / __builtin_sqrtf(ns);
+    n.x *= inv;
+    n.y *= inv;
+    n.z *= inv;
+}
+// ref .cu:197-219
+PM_DEV float4 random_normal(const ProblemDev& P, int px, int py, Rng& g) {
+    float q1, q2, s;
+    do {
+        q1 = 2.0f * rng_uniform(g) - 1.0f;
+        q2 = 2.0f * rng_uniform(g) - 1.0f;
+        s = q1 * q1 + q2 * q2;
+    } while (s >= 1.0f);
+    const float sq = __builtin_sqrtf(1.0f - s);
+    float4 n;
+    n.x = (2.0f * q1) * sq;
+    n.y = (2.0f * q2) * sq;
+    n.z = 1.0f - 2.0f * s;
+    n.w = 0.0f;
+    const float v0 = ((float)px - P.cam.K[2]) / P.cam.K[0];
+    const float v1 = ((float)py - P.cam.K[5]) / P.cam.K[4];
+    const float dp = (n.x * v0 + n.y * v1) + n.z * 1.0f;
+    if (dp > 0.0f) {
+        n.x = -n.x;
+        n.y = -n.y;
+        n.z = -n.z;
+    }
+    normalize3(n);
+    return n;
+}
+// ref .cu:460-495
+PM_DEV float4 perturbed_normal(const ProblemDev& P, int px, int py, const float4 normal, Rng& g, float perturbation) {
+    const float v0 = ((float)px - P.cam.K[2]) / P.cam.K[0];
+    const float v1 = ((float)py - P.cam.K[5]) / P.cam.K[4];
+    const float a1 = (rng_uniform(g) - 0.5f) * perturbation;
+    const float a2 = (rng_uniform(g) - 0.5f) * perturbation;
+    const float a3 = (rng_uniform(g) - 0.5f) * perturbation;
+    const float s1 = d_sin(a1), s2 = d_sin(a2), s3 = d_sin(a3);
+    const float c1 = d_cos(a1), c2 = d_cos(a2), c3 = d_cos(a3);
+    const float R0 = c2 * c3;
+    const float R1 = (c3 * s1) * s2 - c1 * s3;
+    const float R2 = s1 * s3 + (c1 * c3) * s2;
+    const float R3 = c2 * s3;
+    const float R4 = c1 * c3 + (s1 * s2) * s3;
+    const float R5 = (c1 * s2) * s3 - c3 * s1;
+    const float R6 = -s2;
+    const float R7 = c2 * s1;
+    const float R8 = c1 * c2;
+    float4 np;
+    np.x = (R0 * normal.x + R1 * normal.y) + R2 * normal.z;
+    np.y = (R3 * normal.x + R4 * normal.y) + R5 * normal.z;
+    np.z = (R6 * normal.x + R7 * normal.y) + R8 * normal.z;
+    np.w = normal.w;
+    const float dp = (np.x * v0 + np.y * v1) + np.z * 1.0f;
+    if (dp >= 0.0f) return normal;
+    normalize3(np);
+    return np;
+}
+
+// ---------------------------------------------------------------------------
+// reference-window statistics (hypothesis independent; ref .cu:318-323 and the
+// reference-image terms of :363-395).  Kept in registers for the whole kernel:
+// the reference recomputes them for each of the 14*V evaluations per pixel.
+// ---------------------------------------------------------------------------
+struct RefWin {
+    float w[36];
+    float wr[36];
+    float inv_w, mean_r, var_r;
+};
+
+PM_DEV void ref_window(const ProblemDev& P, int px, int py, int step, int radius, float two_ss, float two_sc, RefWin& rw) {
+    const float* base = P.ref_img + (long)py * P.ref_pitch + px;
+    const float rc = base[0];
+    float sw = 0.0f, swr = 0.0f, swrr = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        float pw = 0.0f, pwr = 0.0f, pwrr = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const int dx = a * step - radius, dy = b * step - radius;
+            const float r = base[(long)dy * P.ref_pitch + dx];
+            const float sd = __builtin_sqrtf((float)dx * (float)dx + (float)dy * (float)dy);
+            const float e = (-sd) / two_ss - __builtin_fabsf(r - rc) / two_sc;
+            const float w = d_exp(e);
+            const float wr = w * r;
+            rw.w[a * 6 + b] = w;
+            rw.wr[a * 6 + b] = wr;
+            pw += w;
+            pwr += wr;
+            pwrr = __builtin_fmaf(wr, r, pwrr);
+        }
+        sw += pw;
+        swr += pwr;
+        swrr += pwrr;
+    }
+    rw.inv_w = 1.0f / sw;
+    rw.mean_r = swr * rw.inv_w;
+    const float mrr = swrr * rw.inv_w;
+    rw.var_r = __builtin_fmaf(-rw.mean_r, rw.mean_r, mrr);
+}
+
+struct __attribute__((packed, aligned(4))) f2u {
+    float a, b;
+};
+
+// software bilinear fetch with clamp addressing (CUDA tex2D(t, x+0.5, y+0.5),
+// linear filter; ref .cu:377, SURVEY a-2).  The image carries a one-texel
+// replicated apron, so clamping the coordinate to [-1, w-1] x [-1, h-1] makes
+// all four taps in-bounds and two 8-byte loads fetch them.
+PM_DEV float bilinear(const ViewDev& vw, float sx, float sy) {
+    float cx = (sx >= -1.0f) ? sx : -1.0f;
+    cx = (cx <= vw.wm1) ? cx : vw.wm1;
+    float cy = (sy >= -1.0f) ? sy : -1.0f;
+    cy = (cy <= vw.hm1) ? cy : vw.hm1;
+    const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy);
+    const float ax = cx - fx, ay = cy - fy;
+    const int ix = (int)fx, iy = (int)fy;
+    const float* p0 = vw.img + ((long)iy * vw.pitch + ix);
+    const f2u r0 = *(const f2u*)p0;
+    const f2u r1 = *(const f2u*)(p0 + vw.pitch);
+    const float top = __builtin_fmaf(ax, r0.b - r0.a, r0.a);
+    const float bot = __builtin_fmaf(ax, r1.b - r1.a, r1.a);
+    return __builtin_fmaf(ay, bot - top, top);
+}
+
+// plane -> m = (n^T K_r^-1) / d, shared by all views of one hypothesis
+PM_DEV void plane_to_m(const ProblemDev& P, const float4 pl, float& m0, float& m1, float& m2) {
+    const float inv_d = 1.0f / pl.w;
+    m0 = (pl.x * P.ifx) * inv_d;
+    m1 = (pl.y * P.ify) * inv_d;
+    m2 = __builtin_fmaf(-pl.y, P.cyfy, __builtin_fmaf(-pl.x, P.cxfx, pl.z)) * inv_d;
+}
+
+// ref .cu:325-414 ComputeBilateralNCC for one (hypothesis, source view)
+PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int step, int radius, float m0, float m1, float m2) {
+    const float H0 = __builtin_fmaf(-vw.b[0], m0, vw.A[0]);
+    const float H1 = __builtin_fmaf(-vw.b[0], m1, vw.A[1]);
+    const float H2 = __builtin_fmaf(-vw.b[0], m2, vw.A[2]);
+    const float H3 = __builtin_fmaf(-vw.b[1], m0, vw.A[3]);
+    const float H4 = __builtin_fmaf(-vw.b[1], m1, vw.A[4]);
+    const float H5 = __builtin_fmaf(-vw.b[1], m2, vw.A[5]);
+    const float H6 = __builtin_fmaf(-vw.b[2], m0, vw.A[6]);
+    const float H7 = __builtin_fmaf(-vw.b[2], m1, vw.A[7]);
+    const float H8 = __builtin_fmaf(-vw.b[2], m2, vw.A[8]);
+    const float fpx = (float)px, fpy = (float)py;
+    {
+        const float X = __builtin_fmaf(H1, fpy, __builtin_fmaf(H0, fpx, H2));
+        const float Y = __builtin_fmaf(H4, fpy, __builtin_fmaf(H3, fpx, H5));
+        const float Z = __builtin_fmaf(H7, fpy, __builtin_fmaf(H6, fpx, H8));
+        const float rz = d_rcp(Z);
+        const float cx = X * rz, cy = Y * rz;
+        if (!(cx >= 0.0f && cx < vw.wf && cy >= 0.0f && cy < vw.hf)) return 2.0f;  // ref .cu:351-353
+    }
+    float T1 = 0.0f, T2 = 0.0f, T3 = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const float tx = (float)(px + a * step - radius);
+        const float Cx = __builtin_fmaf(H0, tx, H2);
+        const float Cy = __builtin_fmaf(H3, tx, H5);
+        const float Cz = __builtin_fmaf(H6, tx, H8);
+        float P1 = 0.0f, P2 = 0.0f, P3 = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const float ty = (float)(py + b * step - radius);
+            const float X = __builtin_fmaf(H1, ty, Cx);
+            const float Y = __builtin_fmaf(H4, ty, Cy);
+            const float Z = __builtin_fmaf(H7, ty, Cz);
+            const float rz = d_rcp(Z);
+            const float s = bilinear(vw, X * rz, Y * rz);
+            const float w = rw.w[a * 6 + b];
+            const float ws = w * s;
+            P1 = __builtin_fmaf(w, s, P1);
+            P2 = __builtin_fmaf(ws, s, P2);
+            P3 = __builtin_fmaf(rw.wr[a * 6 + b], s, P3);
+        }
+        T1 += P1;
+        T2 += P2;
+        T3 += P3;
+    }
+    const float ms = T1 * rw.inv_w, mss = T2 * rw.inv_w, mrs = T3 * rw.inv_w;
+    const float var_s = __builtin_fmaf(-ms, ms, mss);
+    if (rw.var_r < 1e-5f || var_s < 1e-5f) return 2.0f;  // ref .cu:406-408
+    const float cov = __builtin_fmaf(-rw.mean_r, ms, mrs);
+    const float den = __builtin_sqrtf(rw.var_r * var_s);
+    float cost = 1.0f - cov / den;
+    cost = (cost < 2.0f) ? cost : 2.0f;  // ref .cu:412
+    cost = (cost > 0.0f) ? cost : 0.0f;
+    return cost;
+}
+
+// ---------------------------------------------------------------------------
+// geometric consistency (ref .cu:582-640)
+// ---------------------------------------------------------------------------
+PM_DEV void backproject(const CamDev& cam, float x, float y, float depth, float& o0, float& o1, float& o2) {
+    const float X0 = (depth * (x - cam.K[2])) / cam.K[0];
+    const float X1 = (depth * (y - cam.K[5])) / cam.K[4];
+    const float X2 = depth;
+    const float t0 = (cam.R[0] * X0 + cam.R[3] * X1) + cam.R[6] * X2;
+    const float t1 = (cam.R[1] * X0 + cam.R[4] * X1) + cam.R[7] * X2;
+    const float t2 = (cam.R[2] * X0 + cam.R[5] * X1) + cam.R[8] * X2;
+    o0 = t0 + cam.C[0];
+    o1 = t1 + cam.C[1];
+    o2 = t2 + cam.C[2];
+}
+PM_DEV void project(const CamDev& cam, float p0, float p1, float p2, float& u, float& v) {
+    const float t0 = ((cam.R[0] * p0 + cam.R[1] * p1) + cam.R[2] * p2) + cam.t[0];
+    const float t1 = ((cam.R[3] * p0 + cam.R[4] * p1) + cam.R[5] * p2) + cam.t[1];
+    const float t2 = ((cam.R[6] * p0 + cam.R[7] * p1) + cam.R[8] * p2) + cam.t[2];
+    const float d = (cam.K[6] * t0 + cam.K[7] * t1) + cam.K[8] * t2;
+    u = ((cam.K[0] * t0 + cam.K[1] * t1) + cam.K[2] * t2) / d;
+    v = ((cam.K[3] * t0 + cam.K[4] * t1) + cam.K[5] * t2) / d;
+}
+PM_DEV float geom_cost(const ProblemDev& P, const ViewDev& vw, const float4 pl, int px, int py) {
+    const float depth = depth_from_plane(P, pl, px, py);
+    float w0, w1, w2;
+    backproject(P.cam, (float)px, (float)py, depth, w0, w1, w2);
+    float su, sv;
+    project(vw.cam, w0, w1, w2, su, sv);
+    float qx = (su >= 0.0f) ? su : 0.0f;
+    qx = (qx <= vw.dwm1) ? qx : vw.dwm1;
+    float qy = (sv >= 0.0f) ? sv : 0.0f;
+    qy = (qy <= vw.dhm1) ? qy : vw.dhm1;
+    const float sd = vw.depth[(long)(int)qy * vw.dw + (int)qx];  // nearest, ref .cu:626
+    if (sd == 0.0f) return 3.0f;
+    float s0, s1, s2;
+    backproject(vw.cam, su, sv, sd, s0, s1, s2);
+    float bu, bv;
+    project(P.cam, s0, s1, s2, bu, bv);
+    const float dc = (float)px - bu, dr = (float)py - bv;
+    const float e = __builtin_sqrtf(dc * dc + dr * dr);
+    return (e < 3.0f) ? e : 3.0f;
+}
+
+}  // namespace pm

@@ -1,0 +1,563 @@
+// pm_kernels.hpp -- the __global__ kernels of the PatchMatch hot path for gfx950.
+//
+// One thread owns one reference pixel (64-wide wavefront = 16x8 pixel patch of
+// one checkerboard colour, or an 8x8 patch for the all-pixel kernels), keeps
+// the 36 bilateral weights of its window in registers, and walks the 14
+// hypotheses of an update through ONE copy of the unrolled 36-tap NCC loop
+// ("slot loop"), so the hot code stays small in the instruction cache.
+// MFMA is not used: there is no dense contraction on this path.
+#pragma once
+
+#include "pm_device.hpp"
+
+namespace pm {
+
+struct LaunchArgs {
+    uint64_t seed;
+    uint32_t launch;
+    int iter;
+    int scale;
+    int parity;   // 0 black ((x+y) even), 1 red
+    int ylimit;   // rows covered by the reference's checkerboard grid (ref .cu:1196)
+    int top_k;
+    float depth_min, depth_max;
+    float two_ss, two_sc;  // 2*sigma_spatial^2, 2*sigma_color^2
+    int init_random;       // InitializeScore branch A (ref .cu:549)
+    int use_prior;         // params.planar_prior
+};
+
+// sampling regions of the checkerboard propagation, ref .cu:769-779
+struct Off {
+    signed char x, y;
+};
+__device__ constexpr Off kDirs[8][12] = {
+    {{-5, -6}, {5, -6}, {-6, -7}, {6, -7}, {-7, -8}, {7, -8}, {-8, -9}, {8, -9}, {-9, -10}, {9, -10}, {-10, -11}, {10, -11}},
+    {{-5, 6}, {5, 6}, {-6, 7}, {6, 7}, {-7, 8}, {7, 8}, {-8, 9}, {8, 9}, {-9, 10}, {9, 10}, {-10, 11}, {10, 11}},
+    {{-6, -5}, {-6, 5}, {-7, -6}, {-7, 6}, {-8, -7}, {-8, 7}, {-9, -8}, {-9, 8}, {-10, -9}, {-10, 9}, {-11, -10}, {-11, 10}},
+    {{6, -5}, {6, 5}, {7, -6}, {7, 6}, {8, -7}, {8, 7}, {9, -8}, {9, 8}, {10, -9}, {10, 9}, {11, -10}, {11, 10}},
+    {{0, -5}, {0, -7}, {0, -9}, {0, -11}, {0, -13}, {0, -15}, {0, -17}, {0, -19}, {0, -21}, {0, -23}, {0, 0}, {0, 0}},
+    {{0, 5}, {0, 7}, {0, 9}, {0, 11}, {0, 13}, {0, 15}, {0, 17}, {0, 19}, {0, 21}, {0, 23}, {0, 0}, {0, 0}},
+    {{-5, 0}, {-7, 0}, {-9, 0}, {-11, 0}, {-13, 0}, {-15, 0}, {-17, 0}, {-19, 0}, {-21, 0}, {-23, 0}, {0, 0}, {0, 0}},
+    {{5, 0}, {7, 0}, {9, 0}, {11, 0}, {13, 0}, {15, 0}, {17, 0}, {19, 0}, {21, 0}, {23, 0}, {0, 0}, {0, 0}}};
+__device__ constexpr int kNumDirs[8] = {12, 12, 12, 12, 10, 10, 10, 10};
+
+// pixel owned by this thread in a checkerboard launch: a wave covers a 16x8
+// patch (64 pixels of one colour), a 256-thread block a 32x16 patch.
+PM_DEV bool checker_pixel(const ProblemDev& P, const LaunchArgs& a, int& x, int& y) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    y = blockIdx.y * 16 + (wv >> 1) * 8 + (lane >> 3);
+    x = blockIdx.x * 32 + (wv & 1) * 16 + 2 * (lane & 7);
+    x += (y + a.parity) & 1;
+    return x < P.W && y < P.H && y < a.ylimit;
+}
+// all-pixel launches: wave = 8x8 patch, block = 16x16
+PM_DEV bool dense_pixel(const ProblemDev& P, int& x, int& y) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    y = blockIdx.y * 16 + (wv >> 1) * 8 + (lane >> 3);
+    x = blockIdx.x * 16 + (wv & 1) * 8 + (lane & 7);
+    return x < P.W && y < P.H;
+}
+
+// ---------------------------------------------------------------------------
+// InitializeScore, ref .cu:536-573 (+ :497-534)
+// ---------------------------------------------------------------------------
+template <int MAXV>
+__global__ __launch_bounds__(256) void k_init(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
+    const ProblemDev& P = *Pp;
+    int x, y;
+    if (!dense_pixel(P, x, y)) return;
+    const int idx = y * P.W + x;
+    const int V = P.V;
+    const int step = 2 << a.scale, radius = 5 * step / 2;
+    Rng g = rng_make(a.seed, (uint32_t)idx, a.launch);
+    RefWin rw;
+    ref_window(P, x, y, step, radius, a.two_ss, a.two_sc, rw);
+
+    float4 pl;
+    if (a.init_random) {
+        pl = random_normal(P, x, y, g);
+        const float depth = rng_uniform(g) * (a.depth_max - a.depth_min) + a.depth_min;
+        pl.w = plane_offset(P, x, y, depth, pl);
+    } else if (a.use_prior && S.mask[idx] > 0 && S.costs[idx] >= 0.1f) {
+        const float perturbation = 0.02f;
+        const float4 pp = S.prior[idx];
+        float dpert = pp.w;
+        const float dmin_p = (1.0f - 3.0f * perturbation) * dpert;
+        const float dmax_p = (1.0f + 3.0f * perturbation) * dpert;
+        dpert = rng_uniform(g) * (dmax_p - dmin_p) + dmin_p;
+        pl = perturbed_normal(P, x, y, pp, g, 0.18849556f);
+        pl.w = dpert;
+    } else {
+        const float4 st = S.planes[idx];
+        pl.x = (P.cam.R[0] * st.x + P.cam.R[1] * st.y) + P.cam.R[2] * st.z;
+        pl.y = (P.cam.R[3] * st.x + P.cam.R[4] * st.y) + P.cam.R[5] * st.z;
+        pl.z = (P.cam.R[6] * st.x + P.cam.R[7] * st.y) + P.cam.R[8] * st.z;
+        pl.w = plane_offset(P, x, y, st.w, pl);
+    }
+    S.planes[idx] = pl;
+
+    float cv[MAXV], sorted[MAXV];
+    float m0, m1, m2;
+    plane_to_m(P, pl, m0, m1, m2);
+    int valid = 0;
+    for (int v = 0; v < V; ++v) {
+        const float c = ncc_cost(P.views[v], rw, x, y, step, radius, m0, m1, m2);
+        cv[v] = c;
+        sorted[v] = c;
+        if (c < 2.0f) valid++;
+    }
+    for (int i = 1; i < V; ++i) {
+        const float tmp = sorted[i];
+        int j = i;
+        for (; j >= 1 && tmp < sorted[j - 1]; --j) sorted[j] = sorted[j - 1];
+        sorted[j] = tmp;
+    }
+    uint32_t sel = 0;
+    float cost = 2.0f;
+    const int top_k = valid < a.top_k ? valid : a.top_k;
+    if (top_k > 0) {
+        float csum = 0.0f;
+        for (int i = 0; i < top_k; ++i) csum += sorted[i];
+        const float thr = sorted[top_k - 1];
+        for (int v = 0; v < V; ++v)
+            if (cv[v] <= thr) sel |= (1u << v);
+        cost = csum / (float)top_k;
+    }
+    S.costs[idx] = cost;
+    S.sel[idx] = sel;
+}
+
+PM_DEV float prior_term(float depth_diff, float angle_cos, float two_ds2, float two_as2) {
+    const float ad = d_acos(angle_cos);
+    return 0.5f + d_exp(-depth_diff * depth_diff / two_ds2) * d_exp(-ad * ad / two_as2);
+}
+
+// ---------------------------------------------------------------------------
+// BlackPixelUpdate / RedPixelUpdate = CheckerboardPropagation +
+// PlaneHypothesisRefinement, ref .cu:724-998 and :642-722
+// ---------------------------------------------------------------------------
+template <bool GEOM, bool PRIOR, int MAXV>
+__global__ __launch_bounds__(256) void k_update(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
+    const ProblemDev& P = *Pp;
+    int x, y;
+    if (!checker_pixel(P, a, x, y)) return;
+    const int W = P.W, Hh = P.H, V = P.V;
+    const int idx = y * W + x;
+    const int step = 2 << a.scale, radius = 5 * step / 2;
+    Rng g = rng_make(a.seed, (uint32_t)idx, a.launch);
+    RefWin rw;
+    ref_window(P, x, y, step, radius, a.two_ss, a.two_sc, rw);
+
+    // -- 8 sampling regions: position of the lowest stored cost (ref .cu:798-816)
+    int pos[8];
+    uint32_t flags = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float best = 3.402823466e+38f;
+        int bpos = 0;
+#pragma unroll
+        for (int d = 0; d < kNumDirs[k]; ++d) {
+            const int nx = x + kDirs[k][d].x, ny = y + kDirs[k][d].y;
+            if (nx >= 0 && ny >= 0 && nx < W && ny < Hh) {
+                const int nidx = ny * W + nx;
+                const float nc = S.costs[nidx];
+                if (best > nc) {
+                    best = nc;
+                    bpos = nidx;
+                }
+            }
+        }
+        pos[k] = bpos;
+        if (best < 3.402823466e+38f) flags |= (1u << k);
+    }
+
+    float cost_arr[8 * MAXV];
+    int cnt[MAXV];       // good count | bad count << 8   (ref .cu:834-845)
+    float tmpw[MAXV];
+    float probs[MAXV];
+    float view_w[MAXV];
+    for (int v = 0; v < V; ++v) {
+        cnt[v] = 0;
+        tmpw[v] = 0.0f;
+    }
+    // every entry is zeroed as in ref .cu:821: the refinement's geometric term
+    // reads view_w[candidate 0..4], beyond V when V < 5 (ref .cu:689)
+    for (int v = 0; v < MAXV; ++v) view_w[v] = 0.0f;
+    const float thr = 0.8f * d_exp((float)(a.iter * a.iter) / (-90.0f));
+
+    const float4 cur = S.planes[idx];
+    const float depth_sigma = (a.depth_max - a.depth_min) / 64.0f;
+    const float two_ds2 = (2.0f * depth_sigma) * depth_sigma;
+    const float angle_sigma = 0.08726646f;
+    const float two_as2 = (2.0f * angle_sigma) * angle_sigma;
+    const float beta = 0.18f;
+
+    float4 plane_now = cur, base_n = cur, n_rand = cur, n_pert = cur, pp = make_float4(0.f, 0.f, 0.f, 0.f);
+    float depth_now = 0.0f, cost_now = 0.0f, geom_now = 0.0f, restricted_cost = 0.0f, weight_norm = 0.0f;
+    float depth_rand = 0.0f, depth_pert = 0.0f, depth_prior = 0.0f, cand_depth = 0.0f;
+    float final_costs[8];
+    uint32_t temp_sel = 0;
+    int min_idx = 0;
+    bool masked = false;
+
+    for (int slot = 0; slot < 14; ++slot) {
+        float4 pl;
+        bool active = true;
+        if (slot < 8) {
+            active = (flags >> slot) & 1u;
+            pl = active ? S.planes[pos[slot]] : make_float4(0.f, 0.f, 0.f, 1.f);
+        } else if (slot == 8) {
+            // ---- view weights (ref .cu:821-878)
+            uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            if (flags & 1u) s0 = S.sel[idx - W];
+            if (flags & 2u) s1 = S.sel[idx + W];
+            if (flags & 4u) s2 = S.sel[idx - 1];
+            if (flags & 8u) s3 = S.sel[idx + 1];
+            float psum = 0.0f;
+            for (int v = 0; v < V; ++v) {
+                float vp = 0.0f;
+                if (flags & 1u) vp += ((s0 >> v) & 1u) ? 0.9f : 0.1f;
+                if (flags & 2u) vp += ((s1 >> v) & 1u) ? 0.9f : 0.1f;
+                if (flags & 4u) vp += ((s2 >> v) & 1u) ? 0.9f : 0.1f;
+                if (flags & 8u) vp += ((s3 >> v) & 1u) ? 0.9f : 0.1f;
+                const int good = cnt[v] & 0xff, bad = cnt[v] >> 8;
+                float pr;
+                if (good > 2 && bad < 3)
+                    pr = (vp * tmpw[v]) / (float)good;
+                else if (bad < 3)
+                    pr = vp * d_exp((thr * thr) / (-0.32f));
+                else
+                    pr = 0.0f;
+                probs[v] = pr;
+                psum += pr;
+            }
+            const float inv = 1.0f / psum;  // 0 * inf = NaN when everything vanished (ref .cu:42-56)
+            float cum = 0.0f;
+            for (int v = 0; v < V; ++v) {
+                cum += probs[v] * inv;
+                probs[v] = cum;
+            }
+            probs[V - 1] = 1.0f;
+            for (int s = 0; s < 15; ++s) {
+                const float rp = rng_uniform(g) - 1.1920928955078125e-7f;
+                for (int v = 0; v < V; ++v)
+                    if (probs[v] > rp) {
+                        view_w[v] += 1.0f;
+                        break;
+                    }
+            }
+            for (int v = 0; v < V; ++v)
+                if (view_w[v] > 0.0f) {
+                    temp_sel |= (1u << v);
+                    weight_norm += view_w[v];
+                }
+            // ---- weighted candidate costs (ref .cu:880-899)
+            for (int i = 0; i < 8; ++i) {
+                const bool fl = (flags >> i) & 1u;
+                float4 cpl = make_float4(0.f, 0.f, 0.f, 1.f);
+                if (GEOM && fl) cpl = S.planes[pos[i]];
+                float fc = 0.0f;
+                for (int v = 0; v < V; ++v) {
+                    if (view_w[v] > 0.0f) {
+                        if (GEOM) {
+                            if (fl)
+                                fc += view_w[v] * (cost_arr[i * MAXV + v] + 0.2f * geom_cost(P, P.views[v], cpl, x, y));
+                            else
+                                fc += view_w[v] * (cost_arr[i * MAXV + v] + 0.1f * 3.0f);
+                        } else {
+                            fc += view_w[v] * cost_arr[i * MAXV + v];
+                        }
+                    }
+                }
+                final_costs[i] = fc / weight_norm;
+            }
+            {
+                float mc = final_costs[0];
+                for (int i = 1; i < 8; ++i)
+                    if (final_costs[i] <= mc) {
+                        mc = final_costs[i];
+                        min_idx = i;
+                    }
+            }
+            pl = cur;
+        } else {
+            if (slot == 9) {
+                // ---- acceptance of the best propagated neighbour (ref .cu:921-991)
+                depth_now = depth_from_plane(P, cur, x, y);
+                if (PRIOR) pp = S.prior[idx];
+                masked = PRIOR && S.mask[idx] > 0;
+                if (PRIOR && !GEOM) {
+                    depth_prior = depth_from_plane(P, pp, x, y);
+                    if (masked) {
+                        float rfc[8];
+                        for (int i = 0; i < 8; ++i) {
+                            rfc[i] = 0.0f;
+                            if ((flags >> i) & 1u) {
+                                const float4 cpl = S.planes[pos[i]];
+                                const float di = depth_from_plane(P, cpl, x, y);
+                                const float ac = (pp.x * cpl.x + pp.y * cpl.y) + pp.z * cpl.z;
+                                const float pr = prior_term(di - depth_prior, ac, two_ds2, two_as2);
+                                rfc[i] = d_exp(-final_costs[i] * final_costs[i] / beta) * pr;
+                            }
+                        }
+                        int max_idx = 0;
+                        float mc = rfc[0];
+                        for (int i = 1; i < 8; ++i)
+                            if (rfc[i] >= mc) {
+                                mc = rfc[i];
+                                max_idx = i;
+                            }
+                        const float ac = (pp.x * cur.x + pp.y * cur.y) + pp.z * cur.z;
+                        const float pr = prior_term(depth_now - depth_prior, ac, two_ds2, two_as2);
+                        const float rc_now = d_exp(-cost_now * cost_now / beta) * pr;
+                        if ((flags >> max_idx) & 1u) {
+                            const float4 cpl = S.planes[pos[max_idx]];
+                            const float db = depth_from_plane(P, cpl, x, y);
+                            if (db >= a.depth_min && db <= a.depth_max && rfc[max_idx] > rc_now) {
+                                // ref .cu:950/961: the shadowed depth_now keeps the old plane's depth
+                                plane_now = cpl;
+                                restricted_cost = rfc[max_idx];
+                                S.sel[idx] = temp_sel;
+                            }
+                        }
+                    } else if ((flags >> min_idx) & 1u) {
+                        const float4 cpl = S.planes[pos[min_idx]];
+                        const float db = depth_from_plane(P, cpl, x, y);
+                        if (db >= a.depth_min && db <= a.depth_max && final_costs[min_idx] < cost_now) {
+                            depth_now = db;
+                            plane_now = cpl;
+                        }
+                    }
+                }
+                if (!PRIOR && ((flags >> min_idx) & 1u)) {
+                    const float4 cpl = S.planes[pos[min_idx]];
+                    const float db = depth_from_plane(P, cpl, x, y);
+                    if (db >= a.depth_min && db <= a.depth_max && final_costs[min_idx] < cost_now) {
+                        depth_now = db;
+                        plane_now = cpl;
+                        cost_now = final_costs[min_idx];
+                        S.sel[idx] = temp_sel;
+                    }
+                }
+                // ---- refinement candidates (ref .cu:644-675)
+                const float perturbation = 0.02f;
+                if (masked) {
+                    depth_prior = depth_from_plane(P, pp, x, y);
+                    depth_rand = (rng_uniform(g) * 6.0f) * depth_sigma + (depth_prior - 3.0f * depth_sigma);
+                    n_rand = perturbed_normal(P, x, y, pp, g, angle_sigma);
+                }
+                depth_rand = rng_uniform(g) * (a.depth_max - a.depth_min) + a.depth_min;
+                n_rand = random_normal(P, x, y, g);
+                const float dmin_p = (1.0f - perturbation) * depth_now;
+                const float dmax_p = (1.0f + perturbation) * depth_now;
+                depth_pert = rng_uniform(g) * (dmax_p - dmin_p) + dmin_p;
+                n_pert = perturbed_normal(P, x, y, plane_now, g, 0.06283185f);
+                base_n = plane_now;
+            }
+            // candidates: (d_rand,n) (d,n_rand) (d_rand,n_rand) (d,n_pert) (d_pert,n)   ref .cu:674-675
+            const int ci = slot - 9;
+            pl = (ci == 1 || ci == 2) ? n_rand : (ci == 3 ? n_pert : base_n);
+            cand_depth = (ci == 0 || ci == 2) ? depth_rand : (ci == 4 ? depth_pert : depth_now);
+            pl.w = plane_offset(P, x, y, cand_depth, pl);
+        }
+
+        float m0, m1, m2;
+        plane_to_m(P, pl, m0, m1, m2);
+        float tc = 0.0f, tg = 0.0f;
+        for (int v = 0; v < V; ++v) {
+            float c;
+            if (active)
+                c = ncc_cost(P.views[v], rw, x, y, step, radius, m0, m1, m2);
+            else
+                c = (slot == 0 && v == 0) ? 2.0f : 0.0f;  // `= {2.0f}` initialiser quirk, ref .cu:795
+            if (slot < 8) {
+                cost_arr[slot * MAXV + v] = c;
+                if (c < thr) {
+                    tmpw[v] += d_exp((c * c) / (-0.18f));
+                    cnt[v] += 1;
+                }
+                if (c > 1.2f) cnt[v] += 256;
+            } else if (slot == 8) {
+                if (GEOM) {
+                    const float gt = 0.2f * geom_cost(P, P.views[v], pl, x, y);
+                    tc += view_w[v] * (c + gt);
+                    tg += view_w[v] * gt;
+                } else {
+                    tc += view_w[v] * c;
+                }
+            } else if (view_w[v] > 0.0f) {
+                if (GEOM) {
+                    const float gt = 0.2f * geom_cost(P, P.views[v], pl, x, y);
+                    tc += view_w[v] * (c + gt);
+                    tg += view_w[slot - 9] * gt;  // candidate index used as view index, ref .cu:689
+                } else {
+                    tc += view_w[v] * c;
+                }
+            }
+        }
+        if (slot == 8) {
+            cost_now = tc / weight_norm;
+            if (GEOM) geom_now = tg / weight_norm;
+        } else if (slot > 8) {
+            tc /= weight_norm;
+            if (GEOM) tg /= weight_norm;
+            const float db = depth_from_plane(P, pl, x, y);
+            if (masked) {
+                const float ac = (pp.x * pl.x + pp.y * pl.y) + pp.z * pl.z;
+                const float pr = prior_term(cand_depth - depth_prior, ac, two_ds2, two_as2);
+                const float rtc = d_exp(-tc * tc / beta) * pr;
+                if (db >= a.depth_min && db <= a.depth_max && rtc > restricted_cost) {
+                    plane_now = pl;
+                    cost_now = tc;
+                }
+            } else if (db >= a.depth_min && db <= a.depth_max && tc < cost_now) {
+                plane_now = pl;
+                cost_now = tc;
+                geom_now = tg;
+            }
+        }
+    }
+    S.costs[idx] = cost_now;
+    S.planes[idx] = plane_now;
+    if (GEOM) S.geom[idx] = geom_now;
+}
+
+// ---------------------------------------------------------------------------
+// GetDepthandNormal, ref .cu:1021-1034
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_depth_normal(const ProblemDev* __restrict__ Pp, StateDev S) {
+    const ProblemDev& P = *Pp;
+    int x, y;
+    if (!dense_pixel(P, x, y)) return;
+    const int idx = y * P.W + x;
+    float4 pl = S.planes[idx];
+    pl.w = depth_from_plane(P, pl, x, y);
+    float4 o;
+    o.x = (P.cam.R[0] * pl.x + P.cam.R[3] * pl.y) + P.cam.R[6] * pl.z;
+    o.y = (P.cam.R[1] * pl.x + P.cam.R[4] * pl.y) + P.cam.R[7] * pl.z;
+    o.z = (P.cam.R[2] * pl.x + P.cam.R[5] * pl.y) + P.cam.R[8] * pl.z;
+    o.w = pl.w;
+    S.planes[idx] = o;
+}
+
+// ---------------------------------------------------------------------------
+// Black/RedPixelFilter = CheckerboardFilter, ref .cu:1036-1174
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_filter(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
+    const ProblemDev& P = *Pp;
+    int x, y;
+    if (!checker_pixel(P, a, x, y)) return;
+    const int W = P.W, Hh = P.H;
+    const int ctr = y * W + x;
+    if (S.costs[ctr] < 0.001f) return;
+    float f[21];
+    int n = 0;
+#define PM_TAP(cond, off) \
+    if (cond) f[n++] = S.planes[ctr + (off)].w;
+    f[n++] = S.planes[ctr].w;
+    PM_TAP(y > 0, -W)
+    PM_TAP(y > 2, -3 * W)
+    PM_TAP(y > 4, -5 * W)
+    PM_TAP(y < Hh - 1, W)
+    PM_TAP(y < Hh - 3, 3 * W)
+    PM_TAP(y < Hh - 5, 5 * W)
+    PM_TAP(x > 0, -1)
+    PM_TAP(x > 2, -3)
+    PM_TAP(x > 4, -5)
+    PM_TAP(x < W - 1, 1)
+    PM_TAP(x < W - 3, 3)
+    PM_TAP(x < W - 5, 5)
+    PM_TAP(y > 0 && x < W - 2, -W + 2)
+    PM_TAP(y < Hh - 1 && x < W - 2, W + 2)
+    PM_TAP(y > 0 && x > 1, -W - 2)
+    PM_TAP(y < Hh - 1 && x > 1, W - 2)
+    PM_TAP(x > 0 && y > 2, -1 - 2 * W)
+    PM_TAP(x < W - 1 && y > 2, 1 - 2 * W)
+    PM_TAP(x > 0 && y < Hh - 2, -1 + 2 * W)
+    PM_TAP(x < W - 1 && y < Hh - 2, 1 + 2 * W)
+#undef PM_TAP
+    for (int i = 1; i < n; ++i) {
+        const float tmp = f[i];
+        int j = i;
+        for (; j >= 1 && tmp < f[j - 1]; --j) f[j] = f[j - 1];
+        f[j] = tmp;
+    }
+    const int mid = n / 2;
+    S.planes[ctr].w = (n % 2 == 0) ? (f[mid - 1] + f[mid]) / 2.0f : f[mid];
+}
+
+// ---------------------------------------------------------------------------
+// data-movement helpers and probes
+// ---------------------------------------------------------------------------
+// replicate-pad a dense W x H image into a (W+2A) x (H+2A) one
+__global__ void k_pad(const float* __restrict__ src, int w, int h, float* __restrict__ dst, int apron) {
+    const int pw = w + 2 * apron, ph = h + 2 * apron;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= pw || y >= ph) return;
+    int sx = x - apron, sy = y - apron;
+    sx = sx < 0 ? 0 : (sx > w - 1 ? w - 1 : sx);
+    sy = sy < 0 ? 0 : (sy > h - 1 ? h - 1 : sy);
+    dst[(long)y * pw + x] = src[(long)sy * w + sx];
+}
+
+__global__ void k_export_depth(const float4* __restrict__ planes, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = planes[i].w;
+}
+
+template <int MAXV>
+__global__ __launch_bounds__(256) void k_eval_ncc(const ProblemDev* __restrict__ Pp, const float4* __restrict__ planes, float* __restrict__ out, LaunchArgs a) {
+    const ProblemDev& P = *Pp;
+    int x, y;
+    if (!dense_pixel(P, x, y)) return;
+    const int idx = y * P.W + x;
+    const int step = 2 << a.scale, radius = 5 * step / 2;
+    RefWin rw;
+    ref_window(P, x, y, step, radius, a.two_ss, a.two_sc, rw);
+    float m0, m1, m2;
+    plane_to_m(P, planes[idx], m0, m1, m2);
+    const long wh = (long)P.W * P.H;
+    for (int v = 0; v < P.V; ++v) out[v * wh + idx] = ncc_cost(P.views[v], rw, x, y, step, radius, m0, m1, m2);
+}
+
+__global__ __launch_bounds__(256) void k_eval_geom(const ProblemDev* __restrict__ Pp, const float4* __restrict__ planes, float* __restrict__ out) {
+    const ProblemDev& P = *Pp;
+    int x, y;
+    if (!dense_pixel(P, x, y)) return;
+    const int idx = y * P.W + x;
+    const long wh = (long)P.W * P.H;
+    const float4 pl = planes[idx];
+    for (int v = 0; v < P.V; ++v) out[v * wh + idx] = geom_cost(P, P.views[v], pl, x, y);
+}
+
+__global__ void k_homography(const ProblemDev* __restrict__ Pp, float4 pl, int v, float* __restrict__ H9) {
+    const ProblemDev& P = *Pp;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float m[3];
+    plane_to_m(P, pl, m[0], m[1], m[2]);
+    for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 3; ++k) H9[r * 3 + k] = __builtin_fmaf(-P.views[v].b[r], m[k], P.views[v].A[r * 3 + k]);
+}
+
+__global__ void k_math(int fn, const float* __restrict__ in, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = in[i];
+    float y;
+    switch (fn) {
+        case 0: y = d_rcp(x); break;
+        case 1: y = d_exp(x); break;
+        case 2: y = d_sin(x); break;
+        case 3: y = d_cos(x); break;
+        default: y = d_acos(x); break;
+    }
+    out[i] = y;
+}
+
+__global__ void k_rng(uint64_t seed, uint32_t pix, uint32_t launch, int n, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Rng g = rng_make(seed, pix, launch);
+    for (int i = 0; i < n; ++i) out[i] = rng_uniform(g);
+}
+
+}  // namespace pm

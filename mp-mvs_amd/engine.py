@@ -1,0 +1,83 @@
+"""Loader of the HIP library (csrc/libmpmvs_hip.so) behind include/mpmvs.h.
+
+There is no CPU fallback: if the library is missing or no HIP device is
+visible, creating a context raises.
+"""
+import ctypes as C
+import os
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmpmvs_hip.so")
+
+# entry points of include/mpmvs.h beyond the set shared with the test oracle
+_P = C.c_void_p
+_EXTRA = {
+    "device_count": (C.c_int, []),
+    "set_src_depths_device": (C.c_int, [_P, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "export_depth_device": (C.c_int, [_P, _P]),
+    "set_profiling": (C.c_int, [_P, C.c_int]),
+    "get_kernel_times": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+}
+ALL_SYMBOLS = ["mpmvs_" + n for n in list(_abi.SIGNATURES) + list(_EXTRA)]
+
+_cache = {}
+
+
+def load():
+    """dlopen the HIP library and bind every entry point; raises if it is not built."""
+    if "lib" in _cache:
+        return _cache["lib"], _cache["fns"]
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"HIP library not built: {LIB_PATH} (run __graft_entry__.build() or make -C mp-mvs_amd/csrc)")
+    lib = C.CDLL(LIB_PATH)
+    fns = _abi.bind(lib, "mpmvs_")
+    for name, (res, args) in _EXTRA.items():
+        fn = getattr(lib, "mpmvs_" + name)
+        fn.restype = res
+        fn.argtypes = args
+        fns[name] = fn
+    _cache["lib"], _cache["fns"] = lib, fns
+    return lib, fns
+
+
+class HipPatchMatch(_abi.PatchMatchHandle):
+    """One PatchMatch context on one MI355X (the device-side half of the
+    reference's PatchMatchCUDA object, reference include/PatchMatch.h:87-154)."""
+
+    def __init__(self, device=0):
+        _, fns = load()
+        ctx = fns["create"](int(device))
+        if not ctx:
+            msg = fns["last_error"](None)
+            raise RuntimeError("mpmvs_create failed: " + (msg.decode() if msg else "unknown"))
+        super().__init__(fns, ctx)
+        self.device = int(device)
+
+    def set_profiling(self, on=True):
+        self._chk(self._f["set_profiling"](self._ctx, 1 if on else 0), "set_profiling")
+
+    def kernel_times(self):
+        ms = (C.c_float * 6)()
+        cnt = (C.c_int * 6)()
+        self._chk(self._f["get_kernel_times"](self._ctx, ms, cnt), "get_kernel_times")
+        return list(ms), list(cnt)
+
+    def set_src_depths_device(self, ptrs, widths, heights):
+        n = len(ptrs)
+        arr = (C.c_void_p * n)(*[int(p) for p in ptrs])
+        ws = (C.c_int * n)(*widths)
+        hs = (C.c_int * n)(*heights)
+        self._chk(self._f["set_src_depths_device"](self._ctx, n, arr, ws, hs), "set_src_depths_device")
+
+    def export_depth_device(self, ptr):
+        self._chk(self._f["export_depth_device"](self._ctx, int(ptr)), "export_depth_device")
+
+
+def device_count():
+    return load()[1]["device_count"]()
+
+
+def create(device=0):
+    return HipPatchMatch(device)

@@ -78,7 +78,7 @@ def render_view(width, height, K, R, Cc, seed, fs):
     rc = np.stack([(u - K[0, 2]) / K[0, 0], (v - K[1, 2]) / K[1, 1], np.ones_like(u)], -1)
     rw = rc @ R  # R^T applied to each ray (row vectors)
     d = np.full(u.shape, 5.0)
-    for _ in range(60):
+    for _ in range(24):
         X = Cc[0] + d * rw[..., 0]
         Y = Cc[1] + d * rw[..., 1]
         d = (height_field(X, Y) - Cc[2]) / rw[..., 2]

@@ -707,7 +707,9 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
             probs[v] = cum;
         }
         probs[V - 1] = 1.0f;
-        for (int v = 0; v < V; ++v) view_w[v] = 0.0f;
+        // all 32 entries are zeroed as in ref .cu:821: the refinement's geometric
+        // term reads view_w[candidate 0..4], beyond V when V < 5 (quirk a-10 iii)
+        for (int v = 0; v < kMaxViews; ++v) view_w[v] = 0.0f;
         for (int s = 0; s < 15; ++s) {
             const float rp = rng_uniform(g) - FLT_EPSILON;
             for (int v = 0; v < V; ++v)

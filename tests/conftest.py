@@ -1,0 +1,33 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pm():
+    return importlib.import_module("mp-mvs_amd")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import binding
+    binding.build()
+    return binding
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """The HIP library; GPU tests fail (not skip) if it is missing."""
+    eng = importlib.import_module("mp-mvs_amd.engine")
+    eng.load()
+    return eng

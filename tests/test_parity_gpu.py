@@ -1,0 +1,329 @@
+"""GPU parity tests: the HIP path, driven through the C ABI (include/mpmvs.h),
+against the CPU oracle on identical seeded inputs.
+
+Tolerance: north_star allows 1e-3 relative on depth/normal maps.  Because both
+sides implement the canonical arithmetic of DESIGN.md section 3 (IEEE fp32,
+explicit fma, own exp/sin/cos/acos/reciprocal, Philox RNG) the tests below ask
+for MORE: bit-for-bit equality of every output array (NaN == NaN).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 12345
+
+
+def bits_equal(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32)) or \
+        np.array_equal(a, b, equal_nan=True)
+
+
+def assert_same(name, got, want):
+    if bits_equal(got, want):
+        return
+    g = np.asarray(got, np.float64).reshape(-1)
+    w = np.asarray(want, np.float64).reshape(-1)
+    bad = ~((g == w) | (np.isnan(g) & np.isnan(w)))
+    i = int(np.flatnonzero(bad)[0])
+    raise AssertionError(f"{name}: {int(bad.sum())} of {bad.size} values differ; first at flat index {i}: "
+                         f"hip={g[i]!r} oracle={w[i]!r}")
+
+
+def make_pair(pm, oracle, engine, W, H, V, spacing=0.5, rot_deg=2.0, src_sizes=None):
+    sc = pm.synth.make_problem_scene(W, H, n_src=min(V, 8), spacing=spacing, rot_deg=rot_deg)
+    ids = [1 + (i % 8) for i in range(V)]
+    cams, imgs = sc.problem(0, ids)
+    gpu = engine.create(0)
+    cpu = oracle.create()
+    gpu.set_views(cams, imgs)
+    cpu.set_views(cams, imgs)
+    dmin, dmax = pm.synth.kernel_depth_range(cams[0])
+    prm = pm.PatchMatchParams(num_images=V + 1, depth_min=float(dmin), depth_max=float(dmax), max_scale=0)
+    return sc, gpu, cpu, prm
+
+
+def random_planes(pm, cam, W, H, rng, dmin, dmax):
+    """camera-frame planes (n, d) through each pixel at a random depth"""
+    n = rng.normal(size=(H, W, 3))
+    n[..., 2] = -np.abs(n[..., 2]) - 0.3
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    depth = rng.uniform(dmin, dmax, size=(H, W))
+    u, v = np.meshgrid(np.arange(W), np.arange(H))
+    X = np.stack([depth * (u - cam.K[2]) / cam.K[0], depth * (v - cam.K[5]) / cam.K[4], depth], -1)
+    d = -(n * X).sum(-1)
+    return np.concatenate([n, d[..., None]], -1).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------
+# canonical math + RNG
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("fn,lo,hi", [(0, -3000.0, 3000.0), (1, -90.0, 5.0), (2, -0.8, 0.8), (3, -0.8, 0.8), (4, -1.1, 1.1)])
+def test_math_bit_exact(pm, oracle, engine, fn, lo, hi):
+    rng = np.random.default_rng(fn)
+    x = rng.uniform(lo, hi, 200000).astype(np.float32)
+    special = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 1e-30, -1e-30, 1e30, np.inf, -np.inf, np.nan, 80.0, -80.0, -80.5, 1.0000001], np.float32)
+    x = np.concatenate([x, special])
+    _, f_gpu = engine.load()
+    got = pm._abi.math_probe(f_gpu, fn, x)
+    want = pm._abi.math_probe(oracle.fns(), fn, x)
+    assert_same(f"math fn {fn}", got, want)
+
+
+def test_rng_bit_exact(pm, oracle, engine):
+    _, f_gpu = engine.load()
+    for seed, pix, launch in [(SEED, 0, 0), (SEED, 12345, 7), (2 ** 40 + 17, 1919999, 22)]:
+        got = pm._abi.rng_probe(f_gpu, seed, pix, launch, 257)
+        want = pm._abi.rng_probe(oracle.fns(), seed, pix, launch, 257)
+        assert_same("rng", got, want)
+        assert got.min() > 0.0 and got.max() <= 1.0
+
+
+# ---------------------------------------------------------------------------
+# T1: deterministic functions
+# ---------------------------------------------------------------------------
+def test_homography_bit_exact(pm, oracle, engine):
+    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, 96, 64, 3)
+    rng = np.random.default_rng(1)
+    planes = random_planes(pm, sc.views[0].cam, 96, 64, rng, prm.depth_min, prm.depth_max)
+    for v in range(3):
+        for (y, x) in [(0, 0), (31, 47), (63, 95)]:
+            assert_same("homography", gpu.homography(planes[y, x], v), cpu.homography(planes[y, x], v))
+
+
+@pytest.mark.parametrize("scale", [0, 1, 2])
+def test_ncc_bit_exact(pm, oracle, engine, scale):
+    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, 96, 64, 3)
+    rng = np.random.default_rng(2 + scale)
+    planes = random_planes(pm, sc.views[0].cam, 96, 64, rng, prm.depth_min, prm.depth_max)
+    got = gpu.eval_ncc(prm, planes, scale)
+    want = cpu.eval_ncc(prm, planes, scale)
+    assert_same(f"ncc scale {scale}", got, want)
+    assert got.min() >= 0.0 and got.max() <= 2.0
+    assert (got < 2.0).mean() > 0.3  # not everything is the out-of-view sentinel
+
+
+def test_ncc_true_surface_is_cheap(pm, oracle, engine):
+    """known answer: planes tangent to the rendered surface give a low NCC cost"""
+    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, 160, 120, 4, spacing=0.3, rot_deg=1.0)
+    cam = sc.views[0].cam
+    gt = sc.views[0].gt_depth.astype(np.float64)
+    H, W = gt.shape
+    u, v = np.meshgrid(np.arange(W), np.arange(H))
+    X = np.stack([gt * (u - cam.K[2]) / cam.K[0], gt * (v - cam.K[5]) / cam.K[4], gt], -1)
+    dXdu = np.gradient(X, axis=1)
+    dXdv = np.gradient(X, axis=0)
+    n = np.cross(dXdu, dXdv)
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    n[(n * X).sum(-1) > 0] *= -1
+    d = -(n * X).sum(-1)
+    planes = np.concatenate([n, d[..., None]], -1).astype(np.float32)
+    cost = gpu.eval_ncc(prm, planes, 0)
+    inner = cost[:, 15:-15, 15:-15]
+    assert np.median(inner) < 0.05
+    assert_same("ncc on true surface", cost, cpu.eval_ncc(prm, planes, 0))
+
+
+def test_geom_cost_bit_exact(pm, oracle, engine):
+    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, 96, 64, 3)
+    rng = np.random.default_rng(5)
+    depths = []
+    for i in (1, 2, 3):
+        d = sc.views[i].gt_depth * (1.0 + 0.005 * rng.standard_normal(sc.views[i].gt_depth.shape)).astype(np.float32)
+        d[::7, ::5] = 0.0  # holes: the src_depth == 0 branch (ref .cu:628)
+        depths.append(d)
+    gpu.set_src_depths(depths)
+    cpu.set_src_depths(depths)
+    planes = random_planes(pm, sc.views[0].cam, 96, 64, rng, prm.depth_min, prm.depth_max)
+    got = gpu.eval_geom(prm, planes)
+    want = cpu.eval_geom(prm, planes)
+    assert_same("geom cost", got, want)
+    assert got.max() <= 3.0 and (got < 3.0).mean() > 0.05
+
+
+# ---------------------------------------------------------------------------
+# T2: single kernels from identical state, all three modes
+# ---------------------------------------------------------------------------
+def compare_state(gpu, cpu, what, geom=False):
+    g = gpu.get(geom=geom)
+    c = cpu.get(geom=geom)
+    assert_same(what + " planes", g[0], c[0])
+    assert_same(what + " costs", g[1], c[1])
+    if geom:
+        assert_same(what + " geom costs", g[2], c[2])
+    assert np.array_equal(gpu.get_selected_views(), cpu.get_selected_views()), what + " selected views"
+
+
+@pytest.mark.parametrize("W,H,V", [(96, 64, 3), (97, 33, 2), (70, 50, 1)])
+def test_photometric_steps_bit_exact(pm, oracle, engine, W, H, V):
+    """init -> black -> red -> depth/normal -> filters, compared after every kernel;
+    97x33 exercises the uncovered last row of the reference's checkerboard grid"""
+    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, W, H, V)
+    prm.max_scale = 2
+    launch = 0
+    for h in (gpu, cpu):
+        h.step(prm, SEED, pm.KIND_INIT, 0, 2, launch)
+    compare_state(gpu, cpu, "init")
+    for scale in (2, 0):
+        for it in range(2):
+            for kind in (pm.KIND_BLACK, pm.KIND_RED):
+                launch += 1
+                for h in (gpu, cpu):
+                    h.step(prm, SEED, kind, it, scale, launch)
+                compare_state(gpu, cpu, f"update kind {kind} it {it} scale {scale}")
+    for kind in (pm.KIND_DEPTH_NORMAL, pm.KIND_FILTER_BLACK, pm.KIND_FILTER_RED):
+        launch += 1
+        for h in (gpu, cpu):
+            h.step(prm, SEED, kind, 0, 0, launch)
+        compare_state(gpu, cpu, f"kind {kind}")
+
+
+def _photometric_result(pm, cpu, prm):
+    cpu.run(prm, SEED)
+    return cpu.get()
+
+
+def test_geom_steps_bit_exact(pm, oracle, engine):
+    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, 96, 64, 3)
+    planes, costs = _photometric_result(pm, cpu, prm)
+    rng = np.random.default_rng(7)
+    depths = [sc.views[i].gt_depth * (1.0 + 0.005 * rng.standard_normal((64, 96))).astype(np.float32) for i in (1, 2, 3)]
+    prm.geom_consistency = True
+    prm.max_iterations = 2
+    for h in (gpu, cpu):
+        h.set_src_depths(depths)
+        h.set_state(planes, costs)
+    launch = 0
+    for h in (gpu, cpu):
+        h.step(prm, SEED + 1, pm.KIND_INIT, 0, prm.max_scale, launch)
+    compare_state(gpu, cpu, "geom init", geom=False)
+    for it in range(2):
+        for kind in (pm.KIND_BLACK, pm.KIND_RED):
+            launch += 1
+            for h in (gpu, cpu):
+                h.step(prm, SEED + 1, kind, it, 0, launch)
+            compare_state(gpu, cpu, f"geom update kind {kind} it {it}", geom=True)
+
+
+def _fake_prior(pm, sc, planes_world_depth, costs, rng):
+    """prior planes from the GT surface (camera frame), mask on ~60 % of the pixels"""
+    cam = sc.views[0].cam
+    gt = sc.views[0].gt_depth.astype(np.float64)
+    H, W = gt.shape
+    u, v = np.meshgrid(np.arange(W), np.arange(H))
+    X = np.stack([gt * (u - cam.K[2]) / cam.K[0], gt * (v - cam.K[5]) / cam.K[4], gt], -1)
+    n = np.zeros((H, W, 3))
+    n[..., 2] = -1.0
+    n[..., 0] = 0.05 * rng.standard_normal((H, W))
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    d = -(n * X).sum(-1)
+    prior = np.concatenate([n, d[..., None]], -1).astype(np.float32)
+    mask = (rng.uniform(size=(H, W)) < 0.6).astype(np.uint32) * np.arange(1, H * W + 1, dtype=np.uint32).reshape(H, W)
+    return prior, mask
+
+
+def test_prior_steps_bit_exact(pm, oracle, engine):
+    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, 96, 64, 3)
+    planes, costs = _photometric_result(pm, cpu, prm)
+    sel = cpu.get_selected_views()
+    rng = np.random.default_rng(9)
+    prior, mask = _fake_prior(pm, sc, planes, costs, rng)
+    prm.planar_prior = True
+    for h in (gpu, cpu):
+        h.set_state(planes, costs)
+        h.set_selected_views(sel)
+        h.set_prior(prior, mask)
+    launch = 0
+    for h in (gpu, cpu):
+        h.step(prm, SEED + 2, pm.KIND_INIT, 0, prm.max_scale, launch)
+    compare_state(gpu, cpu, "prior init")
+    for it in range(2):
+        for kind in (pm.KIND_BLACK, pm.KIND_RED):
+            launch += 1
+            for h in (gpu, cpu):
+                h.step(prm, SEED + 2, kind, it, 0, launch)
+            compare_state(gpu, cpu, f"prior update kind {kind} it {it}")
+
+
+# ---------------------------------------------------------------------------
+# T3: whole Run() schedules
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("W,H,V,max_scale", [(160, 120, 4, 0), (128, 96, 8, 2), (80, 60, 9, 0)])
+def test_run_bit_exact(pm, oracle, engine, W, H, V, max_scale):
+    """V = 9 takes the > 8 source-view instantiation of the kernels"""
+    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, W, H, V, spacing=0.4)
+    prm.max_scale = max_scale
+    gpu.run(prm, SEED)
+    cpu.run(prm, SEED)
+    compare_state(gpu, cpu, "run")
+    planes, costs = gpu.get()
+    gt = sc.views[0].gt_depth
+    rel = np.abs(planes[..., 3] - gt) / gt
+    assert (rel < 0.05).mean() > 0.85
+    assert np.all((costs >= 0) & (costs <= 2))
+
+
+def test_mixed_source_sizes_bit_exact(pm, oracle, engine):
+    """sources smaller/larger than the reference image (per-view width/height)"""
+    sc = pm.synth.make_problem_scene(96, 64, n_src=2, spacing=0.5)
+    big = pm.synth.make_scene(120, 80, [(0.5, 0.0, 0.0)], rot_deg=0.0)
+    cams = [sc.views[0].cam, sc.views[1].cam, big.views[0].cam]
+    imgs = [sc.views[0].image, sc.views[1].image, big.views[0].image]
+    dmin, dmax = pm.synth.kernel_depth_range(cams[0])
+    prm = pm.PatchMatchParams(num_images=3, depth_min=float(dmin), depth_max=float(dmax), max_scale=1)
+    gpu, cpu = engine.create(0), oracle.create()
+    for h in (gpu, cpu):
+        h.set_views(cams, imgs)
+        h.run(prm, SEED)
+    compare_state(gpu, cpu, "mixed sizes")
+
+
+def test_full_pipeline_schedule_bit_exact(pm, oracle, engine):
+    """photometric -> geom -> prior re-run on the same context (device state
+    persists between runs, reference src/PatchMatch.cpp:522,604-606)"""
+    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, 96, 64, 3)
+    rng = np.random.default_rng(11)
+    depths = [sc.views[i].gt_depth * (1.0 + 0.005 * rng.standard_normal((64, 96))).astype(np.float32) for i in (1, 2, 3)]
+    for h in (gpu, cpu):
+        prm.geom_consistency = False
+        prm.planar_prior = False
+        prm.max_iterations = 3
+        prm.max_scale = 2
+        h.run(prm, SEED)
+    compare_state(gpu, cpu, "photometric")
+    planes, costs = cpu.get()
+    prior, mask = _fake_prior(pm, sc, planes, costs, rng)
+    for h in (gpu, cpu):
+        h.set_src_depths(depths)
+        prm.geom_consistency = True
+        prm.max_iterations = 2
+        h.run(prm, SEED + 1)
+    compare_state(gpu, cpu, "geom", geom=True)
+    for h in (gpu, cpu):
+        h.set_prior(prior, mask)
+        prm.geom_consistency = False
+        prm.planar_prior = True
+        prm.max_iterations = 3
+        h.run(prm, SEED + 2)
+    compare_state(gpu, cpu, "prior")
+
+
+def test_errors_are_reported_not_fatal(pm, engine):
+    gpu = engine.create(0)
+    prm = pm.PatchMatchParams(num_images=3)
+    with pytest.raises(RuntimeError, match="set_views"):
+        gpu.run(prm, 1)
+    sc = pm.synth.make_problem_scene(64, 48, n_src=2)
+    cams, imgs = sc.problem(0, [1, 2])
+    gpu.set_views(cams, imgs)
+    prm.geom_consistency = True
+    with pytest.raises(RuntimeError, match="depth"):
+        gpu.run(prm, 1)
+    prm.geom_consistency = False
+    prm.planar_prior = True
+    with pytest.raises(RuntimeError, match="prior"):
+        gpu.run(prm, 1)
+    prm.planar_prior = False
+    prm.num_images = 5
+    with pytest.raises(RuntimeError, match="num_images"):
+        gpu.run(prm, 1)
