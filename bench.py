@@ -70,6 +70,9 @@ def cpu_baseline(pm, seed):
     """the oracle (our CPU port; the reference has no CPU path) on a
     bounded sample of the same workload: same schedule, 480x360 instead of 1600x1200"""
     from oracle import binding as ob
+    # the GPU box gives one GPU a share of 16 host cores
+    ncore = min(16, len(os.sched_getaffinity(0)))
+    ob.set_num_threads(ncore)
     w, h = 480, 360
     sc = pm.synth.make_problem_scene(w, h, n_src=V)
     cams, imgs = sc.problem(0, list(range(1, V + 1)))

@@ -389,7 +389,7 @@ static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int 
     const dim3 blk(256);
     const dim3 grid_dense((c->W + 15) / 16, (c->H + 15) / 16);
     const int rows = c->H < a.ylimit ? c->H : a.ylimit;
-    const dim3 grid_chk((c->W + 31) / 32, (rows + 15) / 16);
+    const dim3 grid_chk(((c->W + kChkBlockW - 1) / kChkBlockW) * ((rows + kChkBlockH - 1) / kChkBlockH));
     switch (kind) {
         case MPMVS_KIND_INIT:
             if (c->hP.V <= 8)

@@ -295,27 +295,52 @@ PM_DEV void ref_window(const ProblemDev& P, int px, int py, int step, int radius
     rw.var_r = __builtin_fmaf(-rw.mean_r, rw.mean_r, mrr);
 }
 
-struct __attribute__((packed, aligned(4))) f2u {
-    float a, b;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Per-view source image handle: a 128-bit buffer resource (wave-uniform, built
+// from scalar loads) so the taps are buffer_load_dwordx2 with a 32-bit byte
+// offset instead of flat loads with 64-bit address arithmetic; out-of-range
+// offsets (impossible by construction: the coordinate is clamped first) would
+// read 0 instead of faulting.
+struct SrcTex {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int pitch;      // floats per padded row
+    int row_bytes;  // pitch * 4
+    float wm1, hm1;
 };
+
+PM_DEV SrcTex make_src_tex(const ViewDev& vw) {
+    SrcTex t;
+    t.pitch = vw.pitch;
+    t.row_bytes = vw.pitch * 4;
+    t.wm1 = vw.wm1;
+    t.hm1 = vw.hm1;
+    // resource base = first byte of the padded allocation (texel (-1,-1))
+    const float* base = vw.img - (vw.pitch + 1);
+    const int bytes = vw.pitch * (vw.h + 2 * kSrcApron) * 4;
+    t.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, bytes, 0x00020000);
+    return t;
+}
 
 // software bilinear fetch with clamp addressing (CUDA tex2D(t, x+0.5, y+0.5),
 // linear filter; ref .cu:377, SURVEY a-2).  The image carries a one-texel
 // replicated apron, so clamping the coordinate to [-1, w-1] x [-1, h-1] makes
-// all four taps in-bounds and two 8-byte loads fetch them.
-PM_DEV float bilinear(const ViewDev& vw, float sx, float sy) {
-    float cx = (sx >= -1.0f) ? sx : -1.0f;
-    cx = (cx <= vw.wm1) ? cx : vw.wm1;
-    float cy = (sy >= -1.0f) ? sy : -1.0f;
-    cy = (cy <= vw.hm1) ? cy : vw.hm1;
+// all four taps in-bounds and two 8-byte loads fetch them.  max/min give the
+// canonical NaN -> -1 behaviour of DESIGN.md 3.4 (maxNum returns the number).
+// (A row-pair interleaved layout with ONE 16-byte load per tap was measured
+// slower: 8.9 vs 8.1 ms per update launch, the doubled cache footprint costs
+// more than the halved instruction count saves.)
+PM_DEV float bilinear(const SrcTex& t, float sx, float sy) {
+    const float cx = __builtin_fminf(__builtin_fmaxf(sx, -1.0f), t.wm1);
+    const float cy = __builtin_fminf(__builtin_fmaxf(sy, -1.0f), t.hm1);
     const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy);
     const float ax = cx - fx, ay = cy - fy;
-    const int ix = (int)fx, iy = (int)fy;
-    const float* p0 = vw.img + ((long)iy * vw.pitch + ix);
-    const f2u r0 = *(const f2u*)p0;
-    const f2u r1 = *(const f2u*)(p0 + vw.pitch);
-    const float top = __builtin_fmaf(ax, r0.b - r0.a, r0.a);
-    const float bot = __builtin_fmaf(ax, r1.b - r1.a, r1.a);
+    const int ix1 = (int)fx + 1, iy1 = (int)fy + 1;  // padded coordinates, >= 0
+    const int off = (iy1 * t.pitch + ix1) * 4;
+    const f32x2 r0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(t.rsrc, off, 0, 0));
+    const f32x2 r1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(t.rsrc, off, t.row_bytes, 0));
+    const float top = __builtin_fmaf(ax, r0.y - r0.x, r0.x);
+    const float bot = __builtin_fmaf(ax, r1.y - r1.x, r1.x);
     return __builtin_fmaf(ay, bot - top, top);
 }
 
@@ -339,6 +364,7 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int s
     const float H7 = __builtin_fmaf(-vw.b[2], m1, vw.A[7]);
     const float H8 = __builtin_fmaf(-vw.b[2], m2, vw.A[8]);
     const float fpx = (float)px, fpy = (float)py;
+    const SrcTex tex = make_src_tex(vw);
     {
         const float X = __builtin_fmaf(H1, fpy, __builtin_fmaf(H0, fpx, H2));
         const float Y = __builtin_fmaf(H4, fpy, __builtin_fmaf(H3, fpx, H5));
@@ -362,7 +388,7 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int s
             const float Y = __builtin_fmaf(H4, ty, Cy);
             const float Z = __builtin_fmaf(H7, ty, Cz);
             const float rz = d_rcp(Z);
-            const float s = bilinear(vw, X * rz, Y * rz);
+            const float s = bilinear(tex, X * rz, Y * rz);
             const float w = rw.w[a * 6 + b];
             const float ws = w * s;
             P1 = __builtin_fmaf(w, s, P1);

@@ -10,6 +10,12 @@
 
 #include "pm_device.hpp"
 
+// minimum waves per SIMD the hot kernels are compiled for (caps the VGPR budget;
+// measured: 2 -> 245 VGPR no hot-loop spills 9.5 ms, 3 -> 168 VGPR 13.6 ms, 4 -> 128 VGPR 14.5 ms)
+#ifndef PM_WAVES_PER_SIMD
+#define PM_WAVES_PER_SIMD 2
+#endif
+
 namespace pm {
 
 struct LaunchArgs {
@@ -41,12 +47,34 @@ __device__ constexpr Off kDirs[8][12] = {
     {{5, 0}, {7, 0}, {9, 0}, {11, 0}, {13, 0}, {15, 0}, {17, 0}, {19, 0}, {21, 0}, {23, 0}, {0, 0}, {0, 0}}};
 __device__ constexpr int kNumDirs[8] = {12, 12, 12, 12, 10, 10, 10, 10};
 
-// pixel owned by this thread in a checkerboard launch: a wave covers a 16x8
-// patch (64 pixels of one colour), a 256-thread block a 32x16 patch.
+// Wave shape of the checkerboard launches: PM_WAVE_ROWS rows of 64/PM_WAVE_ROWS
+// same-colour pixels; a 256-thread block stacks its 4 waves vertically.
+// Measured (update launch, cfg 1): 8 rows (16x8 patch) 8.13 ms, 4 rows 8.45,
+// 2 rows 8.59, 1 row 8.87 -- compact 2-D patches reuse more L1 lines between taps.
+#ifndef PM_WAVE_ROWS
+#define PM_WAVE_ROWS 8
+#endif
+constexpr int kLanesPerRow = 64 / PM_WAVE_ROWS;
+constexpr int kChkBlockW = 2 * kLanesPerRow;   // pixels
+constexpr int kChkBlockH = 4 * PM_WAVE_ROWS;   // pixels
+
+// Blocks are dealt round-robin to the 8 XCDs (block b and b+8 share an L2):
+// renumber so that each XCD works through one contiguous run of the raster
+// order, i.e. one horizontal band of the image whose source footprints overlap
+// in that XCD's L2 (9.49 -> 8.13 ms per update launch).  Bijective for any
+// block count; speed only, never correctness: every pixel is visited once.
+PM_DEV int xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7, xcd = id & 7, k = id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 PM_DEV bool checker_pixel(const ProblemDev& P, const LaunchArgs& a, int& x, int& y) {
+    const int nbx = (P.W + kChkBlockW - 1) / kChkBlockW;
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int by = b / nbx, bx = b - by * nbx;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    y = blockIdx.y * 16 + (wv >> 1) * 8 + (lane >> 3);
-    x = blockIdx.x * 32 + (wv & 1) * 16 + 2 * (lane & 7);
+    y = by * kChkBlockH + wv * PM_WAVE_ROWS + lane / kLanesPerRow;
+    x = bx * kChkBlockW + 2 * (lane % kLanesPerRow);
     x += (y + a.parity) & 1;
     return x < P.W && y < P.H && y < a.ylimit;
 }
@@ -62,7 +90,7 @@ PM_DEV bool dense_pixel(const ProblemDev& P, int& x, int& y) {
 // InitializeScore, ref .cu:536-573 (+ :497-534)
 // ---------------------------------------------------------------------------
 template <int MAXV>
-__global__ __launch_bounds__(256) void k_init(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
+__global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_init(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
     const ProblemDev& P = *Pp;
     int x, y;
     if (!dense_pixel(P, x, y)) return;
@@ -137,7 +165,7 @@ PM_DEV float prior_term(float depth_diff, float angle_cos, float two_ds2, float 
 // PlaneHypothesisRefinement, ref .cu:724-998 and :642-722
 // ---------------------------------------------------------------------------
 template <bool GEOM, bool PRIOR, int MAXV>
-__global__ __launch_bounds__(256) void k_update(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
+__global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
     const ProblemDev& P = *Pp;
     int x, y;
     if (!checker_pixel(P, a, x, y)) return;
@@ -365,6 +393,10 @@ __global__ __launch_bounds__(256) void k_update(const ProblemDev* __restrict__ P
         plane_to_m(P, pl, m0, m1, m2);
         float tc = 0.0f, tg = 0.0f;
         for (int v = 0; v < V; ++v) {
+            // From slot 8 on a view with weight 0 contributes exactly +0.0 to
+            // every sum below (all costs are finite), so its evaluation is dead
+            // work; the reference computes it regardless (ref .cu:681,903).
+            if (slot >= 8 && !(view_w[v] > 0.0f)) continue;
             float c;
             if (active)
                 c = ncc_cost(P.views[v], rw, x, y, step, radius, m0, m1, m2);
@@ -506,7 +538,7 @@ __global__ void k_export_depth(const float4* __restrict__ planes, float* __restr
 }
 
 template <int MAXV>
-__global__ __launch_bounds__(256) void k_eval_ncc(const ProblemDev* __restrict__ Pp, const float4* __restrict__ planes, float* __restrict__ out, LaunchArgs a) {
+__global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_eval_ncc(const ProblemDev* __restrict__ Pp, const float4* __restrict__ planes, float* __restrict__ out, LaunchArgs a) {
     const ProblemDev& P = *Pp;
     int x, y;
     if (!dense_pixel(P, x, y)) return;

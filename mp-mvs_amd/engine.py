@@ -29,9 +29,10 @@ def load():
     """dlopen the HIP library and bind every entry point; raises if it is not built."""
     if "lib" in _cache:
         return _cache["lib"], _cache["fns"]
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"HIP library not built: {LIB_PATH} (run __graft_entry__.build() or make -C mp-mvs_amd/csrc)")
-    lib = C.CDLL(LIB_PATH)
+    path = os.environ.get("MPMVS_HIP_LIB", LIB_PATH)  # override: A/B-ing kernel builds
+    if not os.path.exists(path):
+        raise RuntimeError(f"HIP library not built: {path} (run __graft_entry__.build() or make -C mp-mvs_amd/csrc)")
+    lib = C.CDLL(path)
     fns = _abi.bind(lib, "mpmvs_")
     for name, (res, args) in _EXTRA.items():
         fn = getattr(lib, "mpmvs_" + name)
