@@ -31,10 +31,10 @@ PEAK_VALU_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector
 PEAK_HBM_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak
 
 
-def load_scene(pm, w, h, v):
+def load_scene(pm, w, h, v, quantize):
     """seeded synthetic scene, cached on local disk (rendering 9 x 1600x1200 takes ~30 s of numpy)"""
     cache_dir = os.path.join(os.environ.get("TMPDIR", "/tmp"), "mpmvs_scene_cache")
-    path = os.path.join(cache_dir, f"scene_{w}x{h}_v{v}_{pm.synth.SCENE_SEED}.npz")
+    path = os.path.join(cache_dir, f"scene_{w}x{h}_v{v}_{pm.synth.SCENE_SEED}_{'u8' if quantize else 'f32'}.npz")
     sc = None
     if os.path.exists(path):
         try:
@@ -50,7 +50,7 @@ def load_scene(pm, w, h, v):
             return cams, imgs, z["gt0"]
         except Exception:
             sc = None
-    sc = pm.synth.make_problem_scene(w, h, n_src=v)
+    sc = pm.synth.make_problem_scene(w, h, n_src=v, quantize=quantize)
     cams, imgs = sc.problem(0, list(range(1, v + 1)))
     try:
         os.makedirs(cache_dir, exist_ok=True)
@@ -66,7 +66,7 @@ def load_scene(pm, w, h, v):
     return cams, imgs, sc.views[0].gt_depth
 
 
-def cpu_baseline(pm, seed):
+def cpu_baseline(pm, seed, quantize):
     """the oracle (our CPU port; the reference has no CPU path) on a
     bounded sample of the same workload: same schedule, 480x360 instead of 1600x1200"""
     from oracle import binding as ob
@@ -74,7 +74,7 @@ def cpu_baseline(pm, seed):
     ncore = min(16, len(os.sched_getaffinity(0)))
     ob.set_num_threads(ncore)
     w, h = 480, 360
-    sc = pm.synth.make_problem_scene(w, h, n_src=V)
+    sc = pm.synth.make_problem_scene(w, h, n_src=V, quantize=quantize)
     cams, imgs = sc.problem(0, list(range(1, V + 1)))
     dmin, dmax = pm.synth.kernel_depth_range(cams[0])
     prm = pm.PatchMatchParams(num_images=V + 1, depth_min=float(dmin), depth_max=float(dmax), max_scale=0, max_iterations=ITERS)
@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--float-images", action="store_true",
+                    help="keep the rendered images as non-integer fp32 (rescaled-image case) instead of 8-bit camera-like images")
     args = ap.parse_args()
 
     import torch
@@ -113,7 +115,8 @@ def main():
     pm = importlib.import_module("mp-mvs_amd")
     engine = importlib.import_module("mp-mvs_amd.engine")
 
-    cams, imgs, gt = load_scene(pm, W, H, V)
+    quantize = not args.float_images
+    cams, imgs, gt = load_scene(pm, W, H, V, quantize)
     dmin, dmax = pm.synth.kernel_depth_range(cams[0])
     prm = pm.PatchMatchParams(num_images=V + 1, depth_min=float(dmin), depth_max=float(dmax), max_scale=0, max_iterations=ITERS)
     ctx = engine.create(local_rank)
@@ -170,7 +173,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic, seeded height-field scene; images " + ("rounded to 8 bits like the reference's imread input" if quantize else "non-integer fp32") + f"; resident texture format {ctx.texture_format()}",
             "config": {"workload": "configs[1]: 1 ref + 8 src views, 1600x1200, single-scale, photometric only, 3 red/black iterations, one Problem per GPU per step",
                        "width": W, "height": H, "src_views": V, "max_scale": 0, "iterations": ITERS},
             "roofline": {
@@ -192,7 +195,7 @@ def main():
             "within_1pct_of_gt": round(within, 4),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pm, seed)
+            out["cpu_baseline"] = cpu_baseline(pm, seed, quantize)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

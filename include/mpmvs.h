@@ -150,6 +150,16 @@ int mpmvs_math(int fn, const void* in, void* out, int n);
 /* first n uniforms of RNG stream (seed, pixel, launch_id) */
 int mpmvs_rng(uint64_t seed, uint32_t pix, uint32_t launch_id, int n, void* out);
 
+/* ---- resident texture format ---------------------------------------------- */
+/* Source images whose pixels are all integers in [0, 255] (the reference's
+ * imread(GRAYSCALE) -> convertTo(CV_32F) path, src/PatchMatch.cpp:877-882) are
+ * kept in HBM as a quad-packed 8-bit texture (one dword load per bilinear tap);
+ * results are bit-identical to the fp32 format.  force_fp32 != 0 before
+ * mpmvs_set_views keeps fp32 regardless.  mpmvs_texture_format returns 1 for
+ * the 8-bit format, 0 for fp32. */
+int mpmvs_set_texture_format(mpmvs_ctx* ctx, int force_fp32);
+int mpmvs_texture_format(mpmvs_ctx* ctx);
+
 /* ---- measurement --------------------------------------------------------- */
 /* HIP-event timing of the launches of the last mpmvs_run, on the context's
  * stream: ms[k] / count[k] per kernel kind (6 entries each). Profiling is off

@@ -4,7 +4,9 @@
 //
 // HBM layout per context:
 //   reference image   (W+40) x (H+40) fp32, replicated apron 20  (window radius <= 20)
-//   source images     (w+2)  x (h+2)  fp32, replicated apron 1   (bilinear clamp for free)
+//   source images     fp32 format: (w+2) x (h+2) fp32, replicated apron 1 (bilinear clamp for free)
+//                     u8 format (all images 8-bit exact): (w+1) x (h+1) dwords, each packing the
+//                     2x2 bilinear footprint of one texel (pm_device.hpp SrcTex8)
 //   source depth maps dense w x h fp32 (geometric consistency only)
 //   planes float4, costs f32, selected views u32, geometric costs f32 [H*W]
 //   prior planes float4 + mask u32 [H*W] (planar prior only)
@@ -34,13 +36,16 @@ struct mpmvs_ctx {
     ProblemDev hP;               // host mirror
     ProblemDev* dP = nullptr;    // device copy
     float* d_ref = nullptr;
-    std::vector<float*> d_src;   // padded source images
+    std::vector<float*> d_src;   // padded source images (fp32 format)
+    std::vector<uint32_t*> d_src8;  // quad-packed u8 source textures (when every image is 8-bit exact)
+    bool all_u8 = false;
     std::vector<float*> d_depth; // dense source depth maps
     StateDev S{};
     float4* d_prior = nullptr;
     uint32_t* d_mask = nullptr;
     bool have_prior = false, have_depths = false;
     bool profiling = false;
+    bool force_f32 = false;  // keep the fp32 texture format even for 8-bit exact images
     float k_ms[6] = {0, 0, 0, 0, 0, 0};
     int k_cnt[6] = {0, 0, 0, 0, 0, 0};
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;  // (kind, (start, stop))
@@ -69,6 +74,9 @@ static void free_views(mpmvs_ctx* c) {
     c->d_ref = nullptr;
     for (float* p : c->d_src) (void)hipFree(p);
     c->d_src.clear();
+    for (uint32_t* p : c->d_src8) (void)hipFree(p);
+    c->d_src8.clear();
+    c->all_u8 = false;
     for (float* p : c->d_depth) (void)hipFree(p);
     c->d_depth.clear();
     if (c->S.planes) (void)hipFree(c->S.planes);
@@ -162,6 +170,21 @@ static int upload_padded(mpmvs_ctx* c, const float* host, size_t pitch, int w, i
     return 0;
 }
 
+// host image (integers 0..255) -> dense staging buffer -> quad-packed u8 texture
+static int upload_quads(mpmvs_ctx* c, const float* host, size_t pitch, int w, int h, uint32_t** out) {
+    float* d_raw = nullptr;
+    HIPCHK(c, hipMalloc(&d_raw, (size_t)w * h * 4));
+    HIPCHK(c, hipMemcpy2DAsync(d_raw, (size_t)w * 4, host, pitch, (size_t)w * 4, h, hipMemcpyHostToDevice, c->stream));
+    uint32_t* d_q = nullptr;
+    HIPCHK(c, hipMalloc(&d_q, (size_t)(w + 1) * (h + 1) * 4));
+    hipLaunchKernelGGL(k_pack_quads, dim3((w + 1 + 255) / 256, h + 1), dim3(256), 0, c->stream, d_raw, w, h, d_q);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(d_raw));
+    *out = d_q;
+    return 0;
+}
+
 extern "C" {
 
 int mpmvs_device_count(void) {
@@ -230,14 +253,39 @@ int mpmvs_set_views(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* 
         c->hP.ref_pitch = c->W + 2 * kRefApron;
         c->hP.ref_img = c->d_ref + (size_t)kRefApron * c->hP.ref_pitch + kRefApron;
     }
-    c->d_src.assign(n - 1, nullptr);
+    // 8-bit exact input (the reference's imread path, ref .cpp:877-882) takes the
+    // quad-packed u8 texture format; anything else stays fp32
+    bool exact = true;
+    for (int v = 1; v < n && exact; ++v) {
+        const int w = cams[v].width, h = cams[v].height;
+        const size_t pitch = pitch_bytes ? pitch_bytes[v] : (size_t)w * 4;
+        for (int y = 0; y < h && exact; ++y) {
+            const float* row = (const float*)((const char*)images[v] + (size_t)y * pitch);
+            for (int x = 0; x < w; ++x) {
+                const float f = row[x];
+                if (!(f >= 0.0f && f <= 255.0f) || f != (float)(int)f) {
+                    exact = false;
+                    break;
+                }
+            }
+        }
+    }
+    if (c->force_f32) exact = false;
+    c->all_u8 = exact;
+    if (exact) c->d_src8.assign(n - 1, nullptr); else c->d_src.assign(n - 1, nullptr);
     for (int v = 1; v < n; ++v) {
         const int w = cams[v].width, h = cams[v].height;
         const size_t pitch = pitch_bytes ? pitch_bytes[v] : (size_t)w * 4;
-        if ((rc = upload_padded(c, images[v], pitch, w, h, kSrcApron, &c->d_src[v - 1]))) return rc;
         ViewDev& o = c->hP.views[v - 1];
-        o.pitch = w + 2 * kSrcApron;
-        o.img = c->d_src[v - 1] + (size_t)kSrcApron * o.pitch + kSrcApron;
+        if (exact) {
+            if ((rc = upload_quads(c, images[v], pitch, w, h, &c->d_src8[v - 1]))) return rc;
+            o.pitch8 = w + 1;
+            o.img8 = c->d_src8[v - 1];
+        } else {
+            if ((rc = upload_padded(c, images[v], pitch, w, h, kSrcApron, &c->d_src[v - 1]))) return rc;
+            o.pitch = w + 2 * kSrcApron;
+            o.img = c->d_src[v - 1] + (size_t)kSrcApron * o.pitch + kSrcApron;
+        }
     }
     const size_t wh = (size_t)c->W * c->H;
     HIPCHK(c, hipMalloc(&c->S.planes, wh * 16));
@@ -355,12 +403,19 @@ static hipEvent_t get_event(mpmvs_ctx* c) {
     return e;
 }
 
+template <bool GEOM, bool PRIOR, bool U8>
+static void launch_update2(mpmvs_ctx* c, dim3 grid, const LaunchArgs& a) {
+    if (c->hP.V <= 8)
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 8, U8>), grid, dim3(256), 0, c->stream, c->dP, c->S, a);
+    else
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, kMaxViews, U8>), grid, dim3(256), 0, c->stream, c->dP, c->S, a);
+}
 template <bool GEOM, bool PRIOR>
 static void launch_update(mpmvs_ctx* c, dim3 grid, const LaunchArgs& a) {
-    if (c->hP.V <= 8)
-        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 8>), grid, dim3(256), 0, c->stream, c->dP, c->S, a);
+    if (c->all_u8)
+        launch_update2<GEOM, PRIOR, true>(c, grid, a);
     else
-        hipLaunchKernelGGL((k_update<GEOM, PRIOR, kMaxViews>), grid, dim3(256), 0, c->stream, c->dP, c->S, a);
+        launch_update2<GEOM, PRIOR, false>(c, grid, a);
 }
 
 static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int kind, int iter, int scale, uint32_t launch) {
@@ -392,10 +447,14 @@ static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int 
     const dim3 grid_chk(((c->W + kChkBlockW - 1) / kChkBlockW) * ((rows + kChkBlockH - 1) / kChkBlockH));
     switch (kind) {
         case MPMVS_KIND_INIT:
-            if (c->hP.V <= 8)
-                hipLaunchKernelGGL((k_init<8>), grid_dense, blk, 0, c->stream, c->dP, c->S, a);
+            if (c->hP.V <= 8 && c->all_u8)
+                hipLaunchKernelGGL((k_init<8, true>), grid_dense, blk, 0, c->stream, c->dP, c->S, a);
+            else if (c->hP.V <= 8)
+                hipLaunchKernelGGL((k_init<8, false>), grid_dense, blk, 0, c->stream, c->dP, c->S, a);
+            else if (c->all_u8)
+                hipLaunchKernelGGL((k_init<kMaxViews, true>), grid_dense, blk, 0, c->stream, c->dP, c->S, a);
             else
-                hipLaunchKernelGGL((k_init<kMaxViews>), grid_dense, blk, 0, c->stream, c->dP, c->S, a);
+                hipLaunchKernelGGL((k_init<kMaxViews, false>), grid_dense, blk, 0, c->stream, c->dP, c->S, a);
             break;
         case MPMVS_KIND_BLACK:
         case MPMVS_KIND_RED:
@@ -530,10 +589,14 @@ int mpmvs_eval_ncc(mpmvs_ctx* c, const mpmvs_params* p, const void* planes_cam4,
     a.two_ss = (2.0f * p->sigma_spatial) * p->sigma_spatial;
     a.two_sc = (2.0f * p->sigma_color) * p->sigma_color;
     const dim3 grid((c->W + 15) / 16, (c->H + 15) / 16);
-    if (V <= 8)
-        hipLaunchKernelGGL((k_eval_ncc<8>), grid, dim3(256), 0, c->stream, c->dP, d_pl, d_out, a);
+    if (V <= 8 && c->all_u8)
+        hipLaunchKernelGGL((k_eval_ncc<8, true>), grid, dim3(256), 0, c->stream, c->dP, d_pl, d_out, a);
+    else if (V <= 8)
+        hipLaunchKernelGGL((k_eval_ncc<8, false>), grid, dim3(256), 0, c->stream, c->dP, d_pl, d_out, a);
+    else if (c->all_u8)
+        hipLaunchKernelGGL((k_eval_ncc<kMaxViews, true>), grid, dim3(256), 0, c->stream, c->dP, d_pl, d_out, a);
     else
-        hipLaunchKernelGGL((k_eval_ncc<kMaxViews>), grid, dim3(256), 0, c->stream, c->dP, d_pl, d_out, a);
+        hipLaunchKernelGGL((k_eval_ncc<kMaxViews, false>), grid, dim3(256), 0, c->stream, c->dP, d_pl, d_out, a);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, d_out, wh * 4 * V, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -606,6 +669,17 @@ int mpmvs_rng(uint64_t seed, uint32_t pix, uint32_t launch_id, int n, void* out)
     if (!rc && hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = -100;
     (void)hipFree(d_out);
     return rc;
+}
+
+int mpmvs_set_texture_format(mpmvs_ctx* c, int force_fp32) {
+    if (!c) return -1;
+    c->force_f32 = force_fp32 != 0;
+    return 0;
+}
+
+int mpmvs_texture_format(mpmvs_ctx* c) {
+    if (!c) return -1;
+    return c->all_u8 ? 1 : 0;
 }
 
 int mpmvs_set_profiling(mpmvs_ctx* c, int enable) {

@@ -36,8 +36,10 @@ struct ViewDev {
     float b[3];        // K_s t_rel
     float wf, hf;      // (float)width, (float)height
     float wm1, hm1;    // (float)(width-1), (float)(height-1)
-    const float* img;  // texel (0,0) of the apron-padded source image
+    const float* img;  // texel (0,0) of the apron-padded source image (fp32 format)
     int pitch;         // floats per padded row
+    const uint32_t* img8;  // quad-packed u8 texture (see SrcTex8) or null
+    int pitch8;            // dwords per row of the quad-packed texture (= w + 1)
     int w, h;
     const float* depth;  // dense source depth map (geometric consistency) or null
     int dw, dh;
@@ -344,6 +346,45 @@ PM_DEV float bilinear(const SrcTex& t, float sx, float sy) {
     return __builtin_fmaf(ay, bot - top, top);
 }
 
+// Quad-packed 8-bit texture, used when every pixel of every source image is an
+// integer in [0, 255] (always true for the reference's input unless it rescales:
+// imread(GRAYSCALE) -> convertTo(CV_32F), ref .cpp:877-882).  Entry (x, y) of the
+// (w+1) x (h+1) array packs the whole bilinear footprint of the padded image P,
+//   byte0 = P[y][x], byte1 = P[y][x+1], byte2 = P[y+1][x], byte3 = P[y+1][x+1],
+// so ONE aligned buffer_load_dword per tap replaces two 8-byte loads at the same
+// cache footprint (4 bytes per texel).  u8 -> fp32 conversion is exact, so both
+// formats give bit-identical results.
+struct SrcTex8 {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int pitch;  // dwords per row
+    float wm1, hm1;
+};
+
+PM_DEV SrcTex8 make_src_tex8(const ViewDev& vw) {
+    SrcTex8 t;
+    t.pitch = vw.pitch8;
+    t.wm1 = vw.wm1;
+    t.hm1 = vw.hm1;
+    const int bytes = vw.pitch8 * (vw.h + 1) * 4;
+    t.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(vw.img8), (short)0, bytes, 0x00020000);
+    return t;
+}
+
+PM_DEV float bilinear(const SrcTex8& t, float sx, float sy) {
+    const float cx = __builtin_fminf(__builtin_fmaxf(sx, -1.0f), t.wm1);
+    const float cy = __builtin_fminf(__builtin_fmaxf(sy, -1.0f), t.hm1);
+    const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy);
+    const float ax = cx - fx, ay = cy - fy;
+    const int ix1 = (int)fx + 1, iy1 = (int)fy + 1;  // padded coordinates, >= 0
+    const int off = (iy1 * t.pitch + ix1) * 4;
+    const uint32_t q = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(t.rsrc, off, 0, 0);
+    const float t00 = (float)(q & 0xffu), t10 = (float)((q >> 8) & 0xffu);
+    const float t01 = (float)((q >> 16) & 0xffu), t11 = (float)(q >> 24);
+    const float top = __builtin_fmaf(ax, t10 - t00, t00);
+    const float bot = __builtin_fmaf(ax, t11 - t01, t01);
+    return __builtin_fmaf(ay, bot - top, top);
+}
+
 // plane -> m = (n^T K_r^-1) / d, shared by all views of one hypothesis
 PM_DEV void plane_to_m(const ProblemDev& P, const float4 pl, float& m0, float& m1, float& m2) {
     const float inv_d = 1.0f / pl.w;
@@ -353,6 +394,7 @@ PM_DEV void plane_to_m(const ProblemDev& P, const float4 pl, float& m0, float& m
 }
 
 // ref .cu:325-414 ComputeBilateralNCC for one (hypothesis, source view)
+template <bool U8>
 PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int step, int radius, float m0, float m1, float m2) {
     const float H0 = __builtin_fmaf(-vw.b[0], m0, vw.A[0]);
     const float H1 = __builtin_fmaf(-vw.b[0], m1, vw.A[1]);
@@ -364,7 +406,12 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int s
     const float H7 = __builtin_fmaf(-vw.b[2], m1, vw.A[7]);
     const float H8 = __builtin_fmaf(-vw.b[2], m2, vw.A[8]);
     const float fpx = (float)px, fpy = (float)py;
-    const SrcTex tex = make_src_tex(vw);
+    const auto tex = [&] {
+        if constexpr (U8)
+            return make_src_tex8(vw);
+        else
+            return make_src_tex(vw);
+    }();
     {
         const float X = __builtin_fmaf(H1, fpy, __builtin_fmaf(H0, fpx, H2));
         const float Y = __builtin_fmaf(H4, fpy, __builtin_fmaf(H3, fpx, H5));

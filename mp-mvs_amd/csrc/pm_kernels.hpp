@@ -89,7 +89,7 @@ PM_DEV bool dense_pixel(const ProblemDev& P, int& x, int& y) {
 // ---------------------------------------------------------------------------
 // InitializeScore, ref .cu:536-573 (+ :497-534)
 // ---------------------------------------------------------------------------
-template <int MAXV>
+template <int MAXV, bool U8>
 __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_init(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
     const ProblemDev& P = *Pp;
     int x, y;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_init(const ProblemDe
     plane_to_m(P, pl, m0, m1, m2);
     int valid = 0;
     for (int v = 0; v < V; ++v) {
-        const float c = ncc_cost(P.views[v], rw, x, y, step, radius, m0, m1, m2);
+        const float c = ncc_cost<U8>(P.views[v], rw, x, y, step, radius, m0, m1, m2);
         cv[v] = c;
         sorted[v] = c;
         if (c < 2.0f) valid++;
@@ -164,7 +164,7 @@ PM_DEV float prior_term(float depth_diff, float angle_cos, float two_ds2, float 
 // BlackPixelUpdate / RedPixelUpdate = CheckerboardPropagation +
 // PlaneHypothesisRefinement, ref .cu:724-998 and :642-722
 // ---------------------------------------------------------------------------
-template <bool GEOM, bool PRIOR, int MAXV>
+template <bool GEOM, bool PRIOR, int MAXV, bool U8>
 __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
     const ProblemDev& P = *Pp;
     int x, y;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
             if (slot >= 8 && !(view_w[v] > 0.0f)) continue;
             float c;
             if (active)
-                c = ncc_cost(P.views[v], rw, x, y, step, radius, m0, m1, m2);
+                c = ncc_cost<U8>(P.views[v], rw, x, y, step, radius, m0, m1, m2);
             else
                 c = (slot == 0 && v == 0) ? 2.0f : 0.0f;  // `= {2.0f}` initialiser quirk, ref .cu:795
             if (slot < 8) {
@@ -532,12 +532,25 @@ __global__ void k_pad(const float* __restrict__ src, int w, int h, float* __rest
     dst[(long)y * pw + x] = src[(long)sy * w + sx];
 }
 
+// dense w x h image of integers in [0,255] -> quad-packed u8 texture (SrcTex8)
+__global__ void k_pack_quads(const float* __restrict__ src, int w, int h, uint32_t* __restrict__ dst) {
+    const int pw = w + 1;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= pw || y >= h + 1) return;
+    // padded P[py][px] = src[clamp(py-1)][clamp(px-1)]
+    const int x0 = x - 1 < 0 ? 0 : x - 1, x1 = x > w - 1 ? w - 1 : x;
+    const int y0 = y - 1 < 0 ? 0 : y - 1, y1 = y > h - 1 ? h - 1 : y;
+    const uint32_t b0 = (uint32_t)src[(long)y0 * w + x0], b1 = (uint32_t)src[(long)y0 * w + x1];
+    const uint32_t b2 = (uint32_t)src[(long)y1 * w + x0], b3 = (uint32_t)src[(long)y1 * w + x1];
+    dst[(long)y * pw + x] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+}
+
 __global__ void k_export_depth(const float4* __restrict__ planes, float* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = planes[i].w;
 }
 
-template <int MAXV>
+template <int MAXV, bool U8>
 __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_eval_ncc(const ProblemDev* __restrict__ Pp, const float4* __restrict__ planes, float* __restrict__ out, LaunchArgs a) {
     const ProblemDev& P = *Pp;
     int x, y;
@@ -549,7 +562,7 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_eval_ncc(const Probl
     float m0, m1, m2;
     plane_to_m(P, planes[idx], m0, m1, m2);
     const long wh = (long)P.W * P.H;
-    for (int v = 0; v < P.V; ++v) out[v * wh + idx] = ncc_cost(P.views[v], rw, x, y, step, radius, m0, m1, m2);
+    for (int v = 0; v < P.V; ++v) out[v * wh + idx] = ncc_cost<U8>(P.views[v], rw, x, y, step, radius, m0, m1, m2);
 }
 
 __global__ __launch_bounds__(256) void k_eval_geom(const ProblemDev* __restrict__ Pp, const float4* __restrict__ planes, float* __restrict__ out) {

@@ -18,6 +18,8 @@ _EXTRA = {
     "set_src_depths_device": (C.c_int, [_P, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "export_depth_device": (C.c_int, [_P, _P]),
     "set_profiling": (C.c_int, [_P, C.c_int]),
+    "set_texture_format": (C.c_int, [_P, C.c_int]),
+    "texture_format": (C.c_int, [_P]),
     "get_kernel_times": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
 }
 ALL_SYMBOLS = ["mpmvs_" + n for n in list(_abi.SIGNATURES) + list(_EXTRA)]
@@ -55,6 +57,13 @@ class HipPatchMatch(_abi.PatchMatchHandle):
             raise RuntimeError("mpmvs_create failed: " + (msg.decode() if msg else "unknown"))
         super().__init__(fns, ctx)
         self.device = int(device)
+
+    def set_texture_format(self, force_fp32):
+        """call before set_views; True keeps the fp32 texture format even for 8-bit exact images"""
+        self._chk(self._f["set_texture_format"](self._ctx, 1 if force_fp32 else 0), "set_texture_format")
+
+    def texture_format(self):
+        return "u8" if self._f["texture_format"](self._ctx) == 1 else "f32"
 
     def set_profiling(self, on=True):
         self._chk(self._f["set_profiling"](self._ctx, 1 if on else 0), "set_profiling")

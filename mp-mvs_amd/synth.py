@@ -88,9 +88,11 @@ def render_view(width, height, K, R, Cc, seed, fs):
     return img.astype(np.float32), d.astype(np.float32)
 
 
-def make_scene(width, height, centers, seed=SCENE_SEED, rot_deg=2.0, depth_min=3.0, depth_max=8.0):
+def make_scene(width, height, centers, seed=SCENE_SEED, rot_deg=2.0, depth_min=3.0, depth_max=8.0, quantize=False):
     """Cameras at `centers` (N x 3 world positions), fx = fy = 0.9 W, principal
-    point at the image centre; camera 0..N-1 in the order given."""
+    point at the image centre; camera 0..N-1 in the order given.  quantize=True
+    rounds the images to integers 0..255 like an 8-bit camera image (what the
+    reference feeds its textures: imread(GRAYSCALE) -> CV_32F, src/PatchMatch.cpp:877-882)."""
     rng = np.random.default_rng(seed)
     fs = width / 1600.0
     K = np.array([[0.9 * width, 0, width / 2.0], [0, 0.9 * width, height / 2.0], [0, 0, 1.0]])
@@ -104,6 +106,8 @@ def make_scene(width, height, centers, seed=SCENE_SEED, rot_deg=2.0, depth_min=3
         Rf = np.array(cam.R, np.float64).reshape(3, 3)
         Cf = np.array(cam.C, np.float64)
         img, gt = render_view(width, height, Kf, Rf, Cf, seed, fs)
+        if quantize:
+            img = np.rint(img).astype(np.float32)
         sc.views.append(View(cam, img, gt, Kf, Rf, Cf))
     return sc
 

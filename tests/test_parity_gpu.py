@@ -30,14 +30,16 @@ def assert_same(name, got, want):
                          f"hip={g[i]!r} oracle={w[i]!r}")
 
 
-def make_pair(pm, oracle, engine, W, H, V, spacing=0.5, rot_deg=2.0, src_sizes=None):
-    sc = pm.synth.make_problem_scene(W, H, n_src=min(V, 8), spacing=spacing, rot_deg=rot_deg)
+def make_pair(pm, oracle, engine, W, H, V, spacing=0.5, rot_deg=2.0, quantize=False):
+    """quantize=True gives 8-bit exact images -> the quad-packed u8 texture format"""
+    sc = pm.synth.make_problem_scene(W, H, n_src=min(V, 8), spacing=spacing, rot_deg=rot_deg, quantize=quantize)
     ids = [1 + (i % 8) for i in range(V)]
     cams, imgs = sc.problem(0, ids)
     gpu = engine.create(0)
     cpu = oracle.create()
     gpu.set_views(cams, imgs)
     cpu.set_views(cams, imgs)
+    assert gpu.texture_format() == ("u8" if quantize else "f32")
     dmin, dmax = pm.synth.kernel_depth_range(cams[0])
     prm = pm.PatchMatchParams(num_images=V + 1, depth_min=float(dmin), depth_max=float(dmax), max_scale=0)
     return sc, gpu, cpu, prm
@@ -91,9 +93,10 @@ def test_homography_bit_exact(pm, oracle, engine):
             assert_same("homography", gpu.homography(planes[y, x], v), cpu.homography(planes[y, x], v))
 
 
+@pytest.mark.parametrize("quantize", [False, True])
 @pytest.mark.parametrize("scale", [0, 1, 2])
-def test_ncc_bit_exact(pm, oracle, engine, scale):
-    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, 96, 64, 3)
+def test_ncc_bit_exact(pm, oracle, engine, scale, quantize):
+    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, 96, 64, 3, quantize=quantize)
     rng = np.random.default_rng(2 + scale)
     planes = random_planes(pm, sc.views[0].cam, 96, 64, rng, prm.depth_min, prm.depth_max)
     got = gpu.eval_ncc(prm, planes, scale)
@@ -154,11 +157,11 @@ def compare_state(gpu, cpu, what, geom=False):
     assert np.array_equal(gpu.get_selected_views(), cpu.get_selected_views()), what + " selected views"
 
 
-@pytest.mark.parametrize("W,H,V", [(96, 64, 3), (97, 33, 2), (70, 50, 1)])
-def test_photometric_steps_bit_exact(pm, oracle, engine, W, H, V):
+@pytest.mark.parametrize("W,H,V,quantize", [(96, 64, 3, False), (97, 33, 2, True), (70, 50, 1, False), (96, 64, 3, True)])
+def test_photometric_steps_bit_exact(pm, oracle, engine, W, H, V, quantize):
     """init -> black -> red -> depth/normal -> filters, compared after every kernel;
     97x33 exercises the uncovered last row of the reference's checkerboard grid"""
-    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, W, H, V)
+    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, W, H, V, quantize=quantize)
     prm.max_scale = 2
     launch = 0
     for h in (gpu, cpu):
@@ -248,10 +251,10 @@ def test_prior_steps_bit_exact(pm, oracle, engine):
 # ---------------------------------------------------------------------------
 # T3: whole Run() schedules
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("W,H,V,max_scale", [(160, 120, 4, 0), (128, 96, 8, 2), (80, 60, 9, 0)])
-def test_run_bit_exact(pm, oracle, engine, W, H, V, max_scale):
+@pytest.mark.parametrize("W,H,V,max_scale,quantize", [(160, 120, 4, 0, False), (128, 96, 8, 2, True), (80, 60, 9, 0, False), (80, 60, 9, 0, True), (160, 120, 8, 0, True)])
+def test_run_bit_exact(pm, oracle, engine, W, H, V, max_scale, quantize):
     """V = 9 takes the > 8 source-view instantiation of the kernels"""
-    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, W, H, V, spacing=0.4)
+    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, W, H, V, spacing=0.4, quantize=quantize)
     prm.max_scale = max_scale
     gpu.run(prm, SEED)
     cpu.run(prm, SEED)
@@ -306,6 +309,30 @@ def test_full_pipeline_schedule_bit_exact(pm, oracle, engine):
         prm.max_iterations = 3
         h.run(prm, SEED + 2)
     compare_state(gpu, cpu, "prior")
+
+
+def test_texture_formats_agree(pm, engine):
+    """8-bit exact images: the quad-packed u8 format and the fp32 format must give
+    identical bits (u8 -> fp32 is exact); non-integer images must fall back to fp32"""
+    sc = pm.synth.make_problem_scene(128, 96, n_src=4, spacing=0.4, quantize=True)
+    cams, imgs = sc.problem(0, [1, 2, 3, 4])
+    dmin, dmax = pm.synth.kernel_depth_range(cams[0])
+    prm = pm.PatchMatchParams(num_images=5, depth_min=float(dmin), depth_max=float(dmax), max_scale=1)
+    a, b = engine.create(0), engine.create(0)
+    b.set_texture_format(True)
+    for h in (a, b):
+        h.set_views(cams, imgs)
+        h.run(prm, SEED)
+    assert a.texture_format() == "u8" and b.texture_format() == "f32"
+    assert_same("u8 vs f32 planes", a.get()[0], b.get()[0])
+    assert_same("u8 vs f32 costs", a.get()[1], b.get()[1])
+    imgs2 = [im.copy() for im in imgs]
+    imgs2[2][5, 7] += 0.5
+    a.set_views(cams, imgs2)
+    assert a.texture_format() == "f32"
+    imgs2[2][5, 7] = 256.0
+    a.set_views(cams, imgs2)
+    assert a.texture_format() == "f32"
 
 
 def test_errors_are_reported_not_fatal(pm, engine):
