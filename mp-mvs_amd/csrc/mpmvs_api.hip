@@ -406,9 +406,9 @@ static hipEvent_t get_event(mpmvs_ctx* c) {
 template <bool GEOM, bool PRIOR, bool U8>
 static void launch_update2(mpmvs_ctx* c, dim3 grid, const LaunchArgs& a) {
     if (c->hP.V <= 8)
-        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 8, U8>), grid, dim3(256), 0, c->stream, c->dP, c->S, a);
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 8, U8>), grid, dim3(256), ncc_lds_bytes(kChkBlockW, kChkBlockH, a.scale), c->stream, c->dP, c->S, a);
     else
-        hipLaunchKernelGGL((k_update<GEOM, PRIOR, kMaxViews, U8>), grid, dim3(256), 0, c->stream, c->dP, c->S, a);
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, kMaxViews, U8>), grid, dim3(256), ncc_lds_bytes(kChkBlockW, kChkBlockH, a.scale), c->stream, c->dP, c->S, a);
 }
 template <bool GEOM, bool PRIOR>
 static void launch_update(mpmvs_ctx* c, dim3 grid, const LaunchArgs& a) {
@@ -448,13 +448,13 @@ static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int 
     switch (kind) {
         case MPMVS_KIND_INIT:
             if (c->hP.V <= 8 && c->all_u8)
-                hipLaunchKernelGGL((k_init<8, true>), grid_dense, blk, 0, c->stream, c->dP, c->S, a);
+                hipLaunchKernelGGL((k_init<8, true>), grid_dense, blk, ncc_lds_bytes(16, 16, a.scale), c->stream, c->dP, c->S, a);
             else if (c->hP.V <= 8)
-                hipLaunchKernelGGL((k_init<8, false>), grid_dense, blk, 0, c->stream, c->dP, c->S, a);
+                hipLaunchKernelGGL((k_init<8, false>), grid_dense, blk, ncc_lds_bytes(16, 16, a.scale), c->stream, c->dP, c->S, a);
             else if (c->all_u8)
-                hipLaunchKernelGGL((k_init<kMaxViews, true>), grid_dense, blk, 0, c->stream, c->dP, c->S, a);
+                hipLaunchKernelGGL((k_init<kMaxViews, true>), grid_dense, blk, ncc_lds_bytes(16, 16, a.scale), c->stream, c->dP, c->S, a);
             else
-                hipLaunchKernelGGL((k_init<kMaxViews, false>), grid_dense, blk, 0, c->stream, c->dP, c->S, a);
+                hipLaunchKernelGGL((k_init<kMaxViews, false>), grid_dense, blk, ncc_lds_bytes(16, 16, a.scale), c->stream, c->dP, c->S, a);
             break;
         case MPMVS_KIND_BLACK:
         case MPMVS_KIND_RED:
@@ -590,13 +590,13 @@ int mpmvs_eval_ncc(mpmvs_ctx* c, const mpmvs_params* p, const void* planes_cam4,
     a.two_sc = (2.0f * p->sigma_color) * p->sigma_color;
     const dim3 grid((c->W + 15) / 16, (c->H + 15) / 16);
     if (V <= 8 && c->all_u8)
-        hipLaunchKernelGGL((k_eval_ncc<8, true>), grid, dim3(256), 0, c->stream, c->dP, d_pl, d_out, a);
+        hipLaunchKernelGGL((k_eval_ncc<8, true>), grid, dim3(256), ncc_lds_bytes(16, 16, scale), c->stream, c->dP, d_pl, d_out, a);
     else if (V <= 8)
-        hipLaunchKernelGGL((k_eval_ncc<8, false>), grid, dim3(256), 0, c->stream, c->dP, d_pl, d_out, a);
+        hipLaunchKernelGGL((k_eval_ncc<8, false>), grid, dim3(256), ncc_lds_bytes(16, 16, scale), c->stream, c->dP, d_pl, d_out, a);
     else if (c->all_u8)
-        hipLaunchKernelGGL((k_eval_ncc<kMaxViews, true>), grid, dim3(256), 0, c->stream, c->dP, d_pl, d_out, a);
+        hipLaunchKernelGGL((k_eval_ncc<kMaxViews, true>), grid, dim3(256), ncc_lds_bytes(16, 16, scale), c->stream, c->dP, d_pl, d_out, a);
     else
-        hipLaunchKernelGGL((k_eval_ncc<kMaxViews, false>), grid, dim3(256), 0, c->stream, c->dP, d_pl, d_out, a);
+        hipLaunchKernelGGL((k_eval_ncc<kMaxViews, false>), grid, dim3(256), ncc_lds_bytes(16, 16, scale), c->stream, c->dP, d_pl, d_out, a);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, d_out, wh * 4 * V, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -256,19 +256,45 @@ PM_DEV float4 perturbed_normal(const ProblemDev& P, int px, int py, const float4
 }
 
 // ---------------------------------------------------------------------------
-// reference-window statistics (hypothesis independent; ref .cu:318-323 and the
-// reference-image terms of :363-395).  Kept in registers for the whole kernel:
-// the reference recomputes them for each of the 14*V evaluations per pixel.
+// Reference-window statistics (hypothesis independent; ref .cu:318-323 and the
+// reference-image terms of :363-395).  The reference recomputes them for each of
+// the 14*V evaluations of a pixel; here they are computed once per pixel and
+// launch and parked in LDS:
+//   * the block's reference-image tile + halo is staged once into LDS
+//     (coalesced rows, read back as the 36 window taps of every pixel),
+//   * the 36 bilateral weights of a pixel live in a per-thread LDS column
+//     ([tap][thread], conflict free), leaving the VGPRs to the gather pipeline
+//     of the NCC loop.
+// LDS layout (one array, floats): [36 * kBlockThreads weights][tile].
 // ---------------------------------------------------------------------------
+constexpr int kBlockThreads = 256;
+
 struct RefWin {
-    float w[36];
-    float wr[36];
+    const float* lw;   // this thread's weight column: lw[tap * kBlockThreads]
+    const float* lt;   // this thread's pixel inside the LDS tile
+    int tpitch;        // tile pitch in floats
     float inv_w, mean_r, var_r;
 };
 
-PM_DEV void ref_window(const ProblemDev& P, int px, int py, int step, int radius, float two_ss, float two_sc, RefWin& rw) {
-    const float* base = P.ref_img + (long)py * P.ref_pitch + px;
-    const float rc = base[0];
+// cooperative load of the tile [x0-radius, x0+BW+radius) x [y0-radius, y0+BH+radius)
+// of the apron-padded reference image; columns/rows beyond the apron (only ever
+// addressed by threads whose pixel lies outside the image) are clamped
+PM_DEV void load_ref_tile(const ProblemDev& P, float* tile, int x0, int y0, int bw, int bh, int radius) {
+    const int tw = bw + 2 * radius, th = bh + 2 * radius;
+    const int xmin = -kRefApron, xmax = P.W + kRefApron - 1, ymin = -kRefApron, ymax = P.H + kRefApron - 1;
+    for (int i = threadIdx.x; i < tw * th; i += kBlockThreads) {
+        const int ty = i / tw, tx = i - ty * tw;
+        int gx = x0 - radius + tx, gy = y0 - radius + ty;
+        gx = gx < xmin ? xmin : (gx > xmax ? xmax : gx);
+        gy = gy < ymin ? ymin : (gy > ymax ? ymax : gy);
+        tile[i] = P.ref_img[(long)gy * P.ref_pitch + gx];
+    }
+}
+
+// weights of pixel (px,py) -> LDS column `lw`; (lx,ly) = position inside the block
+PM_DEV void ref_window(float* lw, const float* tile, int tpitch, int lx, int ly, int step, int radius, float two_ss, float two_sc, RefWin& rw) {
+    const float* ctr = tile + (ly + radius) * tpitch + (lx + radius);
+    const float rc = ctr[0];
     float sw = 0.0f, swr = 0.0f, swrr = 0.0f;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
@@ -276,13 +302,12 @@ PM_DEV void ref_window(const ProblemDev& P, int px, int py, int step, int radius
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
             const int dx = a * step - radius, dy = b * step - radius;
-            const float r = base[(long)dy * P.ref_pitch + dx];
+            const float r = ctr[dy * tpitch + dx];
             const float sd = __builtin_sqrtf((float)dx * (float)dx + (float)dy * (float)dy);
             const float e = (-sd) / two_ss - __builtin_fabsf(r - rc) / two_sc;
             const float w = d_exp(e);
             const float wr = w * r;
-            rw.w[a * 6 + b] = w;
-            rw.wr[a * 6 + b] = wr;
+            lw[(a * 6 + b) * kBlockThreads] = w;
             pw += w;
             pwr += wr;
             pwrr = __builtin_fmaf(wr, r, pwrr);
@@ -291,6 +316,9 @@ PM_DEV void ref_window(const ProblemDev& P, int px, int py, int step, int radius
         swr += pwr;
         swrr += pwrr;
     }
+    rw.lw = lw;
+    rw.lt = ctr;
+    rw.tpitch = tpitch;
     rw.inv_w = 1.0f / sw;
     rw.mean_r = swr * rw.inv_w;
     const float mrr = swrr * rw.inv_w;
@@ -385,6 +413,54 @@ PM_DEV float bilinear(const SrcTex8& t, float sx, float sy) {
     return __builtin_fmaf(ay, bot - top, top);
 }
 
+// split form of bilinear(): issue() computes the address and starts the loads,
+// value() interpolates; lets a whole window column be in flight at once
+template <bool U8>
+struct BilinearTap;
+
+template <>
+struct BilinearTap<false> {
+    float ax, ay;
+    f32x2 r0, r1;
+    PM_DEV void issue(const SrcTex& t, float sx, float sy) {
+        const float cx = __builtin_fminf(__builtin_fmaxf(sx, -1.0f), t.wm1);
+        const float cy = __builtin_fminf(__builtin_fmaxf(sy, -1.0f), t.hm1);
+        const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy);
+        ax = cx - fx;
+        ay = cy - fy;
+        const int off = (((int)fy + 1) * t.pitch + ((int)fx + 1)) * 4;
+        r0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(t.rsrc, off, 0, 0));
+        r1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(t.rsrc, off, t.row_bytes, 0));
+    }
+    PM_DEV float value() const {
+        const float top = __builtin_fmaf(ax, r0.y - r0.x, r0.x);
+        const float bot = __builtin_fmaf(ax, r1.y - r1.x, r1.x);
+        return __builtin_fmaf(ay, bot - top, top);
+    }
+};
+
+template <>
+struct BilinearTap<true> {
+    float ax, ay;
+    uint32_t q;
+    PM_DEV void issue(const SrcTex8& t, float sx, float sy) {
+        const float cx = __builtin_fminf(__builtin_fmaxf(sx, -1.0f), t.wm1);
+        const float cy = __builtin_fminf(__builtin_fmaxf(sy, -1.0f), t.hm1);
+        const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy);
+        ax = cx - fx;
+        ay = cy - fy;
+        const int off = (((int)fy + 1) * t.pitch + ((int)fx + 1)) * 4;
+        q = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(t.rsrc, off, 0, 0);
+    }
+    PM_DEV float value() const {
+        const float t00 = (float)(q & 0xffu), t10 = (float)((q >> 8) & 0xffu);
+        const float t01 = (float)((q >> 16) & 0xffu), t11 = (float)(q >> 24);
+        const float top = __builtin_fmaf(ax, t10 - t00, t00);
+        const float bot = __builtin_fmaf(ax, t11 - t01, t01);
+        return __builtin_fmaf(ay, bot - top, top);
+    }
+};
+
 // plane -> m = (n^T K_r^-1) / d, shared by all views of one hypothesis
 PM_DEV void plane_to_m(const ProblemDev& P, const float4 pl, float& m0, float& m1, float& m2) {
     const float inv_d = 1.0f / pl.w;
@@ -423,11 +499,14 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int s
     float T1 = 0.0f, T2 = 0.0f, T3 = 0.0f;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-        const float tx = (float)(px + a * step - radius);
+        const int dx = a * step - radius;
+        const float tx = (float)(px + dx);
         const float Cx = __builtin_fmaf(H0, tx, H2);
         const float Cy = __builtin_fmaf(H3, tx, H5);
         const float Cz = __builtin_fmaf(H6, tx, H8);
-        float P1 = 0.0f, P2 = 0.0f, P3 = 0.0f;
+        // phase 1: warp the 6 taps of this window column and issue all their
+        // gathers back to back, so one memory round trip covers the column
+        BilinearTap<U8> tap[6];
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
             const float ty = (float)(py + b * step - radius);
@@ -435,12 +514,20 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int s
             const float Y = __builtin_fmaf(H4, ty, Cy);
             const float Z = __builtin_fmaf(H7, ty, Cz);
             const float rz = d_rcp(Z);
-            const float s = bilinear(tex, X * rz, Y * rz);
-            const float w = rw.w[a * 6 + b];
+            tap[b].issue(tex, X * rz, Y * rz);
+        }
+        // phase 2: interpolate and accumulate in the canonical order
+        float P1 = 0.0f, P2 = 0.0f, P3 = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const float s = tap[b].value();
+            const float w = rw.lw[(a * 6 + b) * kBlockThreads];
+            const float r = rw.lt[(b * step - radius) * rw.tpitch + dx];
+            const float wr = w * r;
             const float ws = w * s;
             P1 = __builtin_fmaf(w, s, P1);
             P2 = __builtin_fmaf(ws, s, P2);
-            P3 = __builtin_fmaf(rw.wr[a * 6 + b], s, P3);
+            P3 = __builtin_fmaf(wr, s, P3);
         }
         T1 += P1;
         T2 += P2;

@@ -10,8 +10,9 @@
 
 #include "pm_device.hpp"
 
-// minimum waves per SIMD the hot kernels are compiled for (caps the VGPR budget;
-// measured: 2 -> 245 VGPR no hot-loop spills 9.5 ms, 3 -> 168 VGPR 13.6 ms, 4 -> 128 VGPR 14.5 ms)
+// minimum waves per SIMD the hot kernels are compiled for (caps the VGPR budget).
+// Measured per update launch, cfg 1, u8 textures: 2 waves (256 VGPR, no hot-loop
+// spills) 4.9 ms; 3 waves (168 VGPR, scratch spills inside the tap loop) 7.2 ms.
 #ifndef PM_WAVES_PER_SIMD
 #define PM_WAVES_PER_SIMD 2
 #endif
@@ -68,22 +69,38 @@ PM_DEV int xcd_remap(int id, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-PM_DEV bool checker_pixel(const ProblemDev& P, const LaunchArgs& a, int& x, int& y) {
+PM_DEV bool checker_pixel(const ProblemDev& P, const LaunchArgs& a, int& x, int& y, int& x0, int& y0) {
     const int nbx = (P.W + kChkBlockW - 1) / kChkBlockW;
     const int b = xcd_remap(blockIdx.x, gridDim.x);
     const int by = b / nbx, bx = b - by * nbx;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    y = by * kChkBlockH + wv * PM_WAVE_ROWS + lane / kLanesPerRow;
-    x = bx * kChkBlockW + 2 * (lane % kLanesPerRow);
+    x0 = bx * kChkBlockW;
+    y0 = by * kChkBlockH;
+    y = y0 + wv * PM_WAVE_ROWS + lane / kLanesPerRow;
+    x = x0 + 2 * (lane % kLanesPerRow);
     x += (y + a.parity) & 1;
     return x < P.W && y < P.H && y < a.ylimit;
 }
 // all-pixel launches: wave = 8x8 patch, block = 16x16
-PM_DEV bool dense_pixel(const ProblemDev& P, int& x, int& y) {
+PM_DEV bool dense_pixel(const ProblemDev& P, int& x, int& y, int& x0, int& y0) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    y = blockIdx.y * 16 + (wv >> 1) * 8 + (lane >> 3);
-    x = blockIdx.x * 16 + (wv & 1) * 8 + (lane & 7);
+    x0 = blockIdx.x * 16;
+    y0 = blockIdx.y * 16;
+    y = y0 + (wv >> 1) * 8 + (lane >> 3);
+    x = x0 + (wv & 1) * 8 + (lane & 7);
     return x < P.W && y < P.H;
+}
+PM_DEV bool dense_pixel(const ProblemDev& P, int& x, int& y) {
+    int x0, y0;
+    return dense_pixel(P, x, y, x0, y0);
+}
+
+// dynamic LDS of the NCC kernels: 36 weights per thread + the reference tile
+extern __shared__ float pm_lds[];
+constexpr int kLdsWeightFloats = 36 * kBlockThreads;
+inline size_t ncc_lds_bytes(int bw, int bh, int scale) {
+    const int radius = 5 * (2 << scale) / 2;
+    return (size_t)(kLdsWeightFloats + (bw + 2 * radius) * (bh + 2 * radius)) * sizeof(float);
 }
 
 // ---------------------------------------------------------------------------
@@ -92,14 +109,19 @@ PM_DEV bool dense_pixel(const ProblemDev& P, int& x, int& y) {
 template <int MAXV, bool U8>
 __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_init(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
     const ProblemDev& P = *Pp;
-    int x, y;
-    if (!dense_pixel(P, x, y)) return;
+    int x, y, x0, y0;
+    const bool valid = dense_pixel(P, x, y, x0, y0);
+    const int step = 2 << a.scale, radius = 5 * step / 2;
+    float* tile = pm_lds + kLdsWeightFloats;
+    const int tpitch = 16 + 2 * radius;
+    load_ref_tile(P, tile, x0, y0, 16, 16, radius);
+    __syncthreads();
+    if (!valid) return;
     const int idx = y * P.W + x;
     const int V = P.V;
-    const int step = 2 << a.scale, radius = 5 * step / 2;
     Rng g = rng_make(a.seed, (uint32_t)idx, a.launch);
     RefWin rw;
-    ref_window(P, x, y, step, radius, a.two_ss, a.two_sc, rw);
+    ref_window(pm_lds + threadIdx.x, tile, tpitch, x - x0, y - y0, step, radius, a.two_ss, a.two_sc, rw);
 
     float4 pl;
     if (a.init_random) {
@@ -127,12 +149,12 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_init(const ProblemDe
     float cv[MAXV], sorted[MAXV];
     float m0, m1, m2;
     plane_to_m(P, pl, m0, m1, m2);
-    int valid = 0;
+    int n_valid = 0;
     for (int v = 0; v < V; ++v) {
         const float c = ncc_cost<U8>(P.views[v], rw, x, y, step, radius, m0, m1, m2);
         cv[v] = c;
         sorted[v] = c;
-        if (c < 2.0f) valid++;
+        if (c < 2.0f) n_valid++;
     }
     for (int i = 1; i < V; ++i) {
         const float tmp = sorted[i];
@@ -142,7 +164,7 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_init(const ProblemDe
     }
     uint32_t sel = 0;
     float cost = 2.0f;
-    const int top_k = valid < a.top_k ? valid : a.top_k;
+    const int top_k = n_valid < a.top_k ? n_valid : a.top_k;
     if (top_k > 0) {
         float csum = 0.0f;
         for (int i = 0; i < top_k; ++i) csum += sorted[i];
@@ -167,14 +189,19 @@ PM_DEV float prior_term(float depth_diff, float angle_cos, float two_ds2, float 
 template <bool GEOM, bool PRIOR, int MAXV, bool U8>
 __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
     const ProblemDev& P = *Pp;
-    int x, y;
-    if (!checker_pixel(P, a, x, y)) return;
+    int x, y, x0, y0;
+    const bool valid = checker_pixel(P, a, x, y, x0, y0);
+    const int step = 2 << a.scale, radius = 5 * step / 2;
+    float* tile = pm_lds + kLdsWeightFloats;
+    const int tpitch = kChkBlockW + 2 * radius;
+    load_ref_tile(P, tile, x0, y0, kChkBlockW, kChkBlockH, radius);
+    __syncthreads();
+    if (!valid) return;
     const int W = P.W, Hh = P.H, V = P.V;
     const int idx = y * W + x;
-    const int step = 2 << a.scale, radius = 5 * step / 2;
     Rng g = rng_make(a.seed, (uint32_t)idx, a.launch);
     RefWin rw;
-    ref_window(P, x, y, step, radius, a.two_ss, a.two_sc, rw);
+    ref_window(pm_lds + threadIdx.x, tile, tpitch, x - x0, y - y0, step, radius, a.two_ss, a.two_sc, rw);
 
     // -- 8 sampling regions: position of the lowest stored cost (ref .cu:798-816)
     int pos[8];
@@ -477,8 +504,8 @@ __global__ __launch_bounds__(256) void k_depth_normal(const ProblemDev* __restri
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_filter(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
     const ProblemDev& P = *Pp;
-    int x, y;
-    if (!checker_pixel(P, a, x, y)) return;
+    int x, y, x0, y0;
+    if (!checker_pixel(P, a, x, y, x0, y0)) return;
     const int W = P.W, Hh = P.H;
     const int ctr = y * W + x;
     if (S.costs[ctr] < 0.001f) return;
@@ -553,12 +580,17 @@ __global__ void k_export_depth(const float4* __restrict__ planes, float* __restr
 template <int MAXV, bool U8>
 __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_eval_ncc(const ProblemDev* __restrict__ Pp, const float4* __restrict__ planes, float* __restrict__ out, LaunchArgs a) {
     const ProblemDev& P = *Pp;
-    int x, y;
-    if (!dense_pixel(P, x, y)) return;
-    const int idx = y * P.W + x;
+    int x, y, x0, y0;
+    const bool valid = dense_pixel(P, x, y, x0, y0);
     const int step = 2 << a.scale, radius = 5 * step / 2;
+    float* tile = pm_lds + kLdsWeightFloats;
+    const int tpitch = 16 + 2 * radius;
+    load_ref_tile(P, tile, x0, y0, 16, 16, radius);
+    __syncthreads();
+    if (!valid) return;
+    const int idx = y * P.W + x;
     RefWin rw;
-    ref_window(P, x, y, step, radius, a.two_ss, a.two_sc, rw);
+    ref_window(pm_lds + threadIdx.x, tile, tpitch, x - x0, y - y0, step, radius, a.two_ss, a.two_sc, rw);
     float m0, m1, m2;
     plane_to_m(P, planes[idx], m0, m1, m2);
     const long wh = (long)P.W * P.H;
