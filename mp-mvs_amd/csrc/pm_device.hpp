@@ -327,6 +327,16 @@ PM_DEV void ref_window(float* lw, const float* tile, int tpitch, int lx, int ly,
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// clamp a sample coordinate to [-1, hi]; NaN -> -1.  v_med3_f32
+// returns min3 when an input is NaN, which is exactly that rule.
+PM_DEV float clamp_coord(float s, float hi) { return __builtin_amdgcn_fmed3f(s, -1.0f, hi); }
+
+// byte offset of padded texel (ix1, iy1), 4 bytes per texel; rows and pitch are
+// below 2^24, so the full-rate 24-bit multiply-add replaces v_mul_lo_u32
+PM_DEV int texel_offset(int iy1, int ix1, int pitch) {
+    return (int)((__umul24((unsigned)iy1, (unsigned)pitch) + (unsigned)ix1) << 2);
+}
+
 // Per-view source image handle: a 128-bit buffer resource (wave-uniform, built
 // from scalar loads) so the taps are buffer_load_dwordx2 with a 32-bit byte
 // offset instead of flat loads with 64-bit address arithmetic; out-of-range
@@ -361,12 +371,11 @@ PM_DEV SrcTex make_src_tex(const ViewDev& vw) {
 // slower: 8.9 vs 8.1 ms per update launch, the doubled cache footprint costs
 // more than the halved instruction count saves.)
 PM_DEV float bilinear(const SrcTex& t, float sx, float sy) {
-    const float cx = __builtin_fminf(__builtin_fmaxf(sx, -1.0f), t.wm1);
-    const float cy = __builtin_fminf(__builtin_fmaxf(sy, -1.0f), t.hm1);
+    const float cx = clamp_coord(sx, t.wm1);
+    const float cy = clamp_coord(sy, t.hm1);
     const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy);
     const float ax = cx - fx, ay = cy - fy;
-    const int ix1 = (int)fx + 1, iy1 = (int)fy + 1;  // padded coordinates, >= 0
-    const int off = (iy1 * t.pitch + ix1) * 4;
+    const int off = texel_offset((int)fy + 1, (int)fx + 1, t.pitch);
     const f32x2 r0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(t.rsrc, off, 0, 0));
     const f32x2 r1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(t.rsrc, off, t.row_bytes, 0));
     const float top = __builtin_fmaf(ax, r0.y - r0.x, r0.x);
@@ -399,12 +408,11 @@ PM_DEV SrcTex8 make_src_tex8(const ViewDev& vw) {
 }
 
 PM_DEV float bilinear(const SrcTex8& t, float sx, float sy) {
-    const float cx = __builtin_fminf(__builtin_fmaxf(sx, -1.0f), t.wm1);
-    const float cy = __builtin_fminf(__builtin_fmaxf(sy, -1.0f), t.hm1);
+    const float cx = clamp_coord(sx, t.wm1);
+    const float cy = clamp_coord(sy, t.hm1);
     const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy);
     const float ax = cx - fx, ay = cy - fy;
-    const int ix1 = (int)fx + 1, iy1 = (int)fy + 1;  // padded coordinates, >= 0
-    const int off = (iy1 * t.pitch + ix1) * 4;
+    const int off = texel_offset((int)fy + 1, (int)fx + 1, t.pitch);
     const uint32_t q = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(t.rsrc, off, 0, 0);
     const float t00 = (float)(q & 0xffu), t10 = (float)((q >> 8) & 0xffu);
     const float t01 = (float)((q >> 16) & 0xffu), t11 = (float)(q >> 24);
@@ -423,12 +431,12 @@ struct BilinearTap<false> {
     float ax, ay;
     f32x2 r0, r1;
     PM_DEV void issue(const SrcTex& t, float sx, float sy) {
-        const float cx = __builtin_fminf(__builtin_fmaxf(sx, -1.0f), t.wm1);
-        const float cy = __builtin_fminf(__builtin_fmaxf(sy, -1.0f), t.hm1);
+        const float cx = clamp_coord(sx, t.wm1);
+        const float cy = clamp_coord(sy, t.hm1);
         const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy);
         ax = cx - fx;
         ay = cy - fy;
-        const int off = (((int)fy + 1) * t.pitch + ((int)fx + 1)) * 4;
+        const int off = texel_offset((int)fy + 1, (int)fx + 1, t.pitch);
         r0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(t.rsrc, off, 0, 0));
         r1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(t.rsrc, off, t.row_bytes, 0));
     }
@@ -444,12 +452,12 @@ struct BilinearTap<true> {
     float ax, ay;
     uint32_t q;
     PM_DEV void issue(const SrcTex8& t, float sx, float sy) {
-        const float cx = __builtin_fminf(__builtin_fmaxf(sx, -1.0f), t.wm1);
-        const float cy = __builtin_fminf(__builtin_fmaxf(sy, -1.0f), t.hm1);
+        const float cx = clamp_coord(sx, t.wm1);
+        const float cy = clamp_coord(sy, t.hm1);
         const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy);
         ax = cx - fx;
         ay = cy - fy;
-        const int off = (((int)fy + 1) * t.pitch + ((int)fx + 1)) * 4;
+        const int off = texel_offset((int)fy + 1, (int)fx + 1, t.pitch);
         q = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(t.rsrc, off, 0, 0);
     }
     PM_DEV float value() const {
