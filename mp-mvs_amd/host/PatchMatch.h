@@ -1,0 +1,173 @@
+// PatchMatch.h -- host-side mirror of the reference's PatchMatch.h interface
+// (reference include/PatchMatch.h:29-156) for the MI355X build.
+//
+// Same names, argument meaning and call order as the reference, so that
+// ProcessProblem() reads like the reference's (src/PatchMatch.cpp:506-638):
+//     PatchMatchCUDA MP; MP.SetGeomConsistencyParams(..); MP.PatchMatchInit(..);
+//     MP.AllocatePatchMatch(); MP.CudaMemInit(..); MP.Run(); ... MP.Release(..);
+// Differences, all forced by the platform:
+//   * the private CUDA handles (textures, curandState, device pointers;
+//     reference PatchMatch.h:95-117) are one opaque mpmvs_ctx* (include/mpmvs.h);
+//   * OpenCV is not available on the target image, so cv::Mat / cv::Point /
+//     cv::Rect are replaced by the minimal Image / Point / Rect below and the
+//     Delaunay triangulation + plane fit are our own (planar_prior.cpp);
+//   * scenes are held in memory (Scene::image, ::depth, ::normal, ::cost); the
+//     DMB / JPEG / cam.txt file formats are a "next" row;
+//   * a Run() takes its RNG seed from SetSeed() instead of clock64()
+//     (reference src/PatchMatch.cu:546) and the device from SetDevice()
+//     instead of cudaSetDevice(0) (reference src/PatchMatch.cpp:509).
+#ifndef MPMVS_HOST_PATCHMATCH_H_
+#define MPMVS_HOST_PATCHMATCH_H_
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/mpmvs.h"
+
+struct float4 {
+    float x, y, z, w;
+};
+struct float3 {
+    float x, y, z;
+};
+
+// reference include/PatchMatch.h:35-67, same layouts (they ARE the C-ABI structs)
+typedef mpmvs_camera Camera;
+struct PatchMatchParams : mpmvs_params {
+    PatchMatchParams() {
+        max_iterations = 3;
+        nSizeHalfWindow = 5;
+        num_images = 5;
+        max_image_size = 3200;
+        nSizeStep = 2;
+        sigma_spatial = 5.0f;
+        sigma_color = 3.0f;
+        top_k = 4;
+        depth_min = 0.0f;
+        depth_max = 1.0f;
+        max_scale = 2;
+        scaled_cols = 0.0f;
+        scaled_rows = 0.0f;
+        geom_consistency = 0;
+        geomPlanarPrior = 0;
+        planar_prior = 0;
+    }
+};
+
+struct Point {
+    int x = 0, y = 0;
+    Point() {}
+    Point(int x_, int y_) : x(x_), y(y_) {}
+};
+struct Rect {
+    int x, y, width, height;
+    bool contains(const Point& p) const { return p.x >= x && p.y >= y && p.x < x + width && p.y < y + height; }
+};
+// reference include/PatchMatch.h:69-72
+struct Triangle {
+    Point pt1, pt2, pt3;
+    Triangle(const Point a, const Point b, const Point c) : pt1(a), pt2(b), pt3(c) {}
+};
+
+// dense row-major fp32 image with `ch` interleaved channels (stands in for cv::Mat_<float>)
+struct Image {
+    int rows = 0, cols = 0, ch = 1;
+    std::vector<float> data;
+    Image() {}
+    Image(int r, int c, int channels = 1, float v = 0.0f) : rows(r), cols(c), ch(channels), data((size_t)r * c * channels, v) {}
+    bool empty() const { return data.empty(); }
+    float& at(int r, int c, int k = 0) { return data[((size_t)r * cols + c) * ch + k]; }
+    float at(int r, int c, int k = 0) const { return data[((size_t)r * cols + c) * ch + k]; }
+};
+
+// reference include/utility.h:17-26 (+ in-memory results instead of .dmb files)
+struct Scene {
+    bool estimate = false;
+    int refID = 0;
+    std::vector<int> srcID;  // srcID[0] is the image itself, then its source views
+    Image image;             // grey, fp32 0..255
+    Camera cam{};            // what ReadCamera() would return for this image
+    Image depth;             // last estimated depth map        (depths.dmb)
+    Image normal;            // last estimated world normals    (normals.dmb)
+    Image cost;              // last estimated costs            (costs.dmb)
+    int max_image_size = 3200;
+};
+
+class PatchMatchCUDA {
+   private:
+    int num_img = 0;
+    std::vector<const Image*> images;
+    std::vector<Image> depths;
+    std::vector<Camera> cameras;
+    mpmvs_ctx* ctx = nullptr;  // replaces reference PatchMatch.h:95-117
+    int device = 0;
+    uint64_t seed = 0;
+    std::vector<float4> hostPlaneHypotheses;
+    std::vector<float> hostCosts;
+    std::vector<float> hostGeomCosts;
+    std::vector<float4> hostPriorPlanes;
+    std::vector<unsigned int> hostPlaneMask;
+    PatchMatchParams params;
+    std::string input_folder, output_folder;
+    void check(int rc, const char* what);
+
+   public:
+    ~PatchMatchCUDA();
+    void SetDevice(int dev) { device = dev; }
+    void SetSeed(uint64_t s) { seed = s; }
+    void SetMaxScale(int s) { params.max_scale = s; }  // the reference has no setter
+    const PatchMatchParams& GetParams() const { return params; }
+
+    void SetGeomConsistencyParams(bool geom_consistency, bool planar_prior);
+    void SetPlanarPriorParams();
+    void SetFolder(const std::string& in, const std::string& out);
+    void PatchMatchInit(std::vector<Scene>& Scenes, const int ID);
+    void AllocatePatchMatch();
+    void CudaMemInit(Scene& scene);
+    void CudaPlanarPriorInitialization(const std::vector<float4>& PlaneParams, const Image& masks);
+    void Run();
+
+    float GetDepthFromPlaneParam(const float4 plane_hypothesis, const int x, const int y);
+    float GetMinDepth();
+    float GetMaxDepth();
+    int GetReferenceImageWidth();
+    int GetReferenceImageHeight();
+    const Image& GetReferenceImage();
+    const Camera& GetReferenceCamera() const { return cameras[0]; }
+    float4 GetPlaneHypothesis(const int index);
+    float GetCost(const int index);
+    float GetGeomCost(const int index);
+
+    float4 GetPriorPlaneParams(const Triangle triangle, int width);
+    std::vector<Triangle> DelaunayTriangulation(const Rect boundRC, const std::vector<Point>& points);
+    void GetTriangulateVertices(std::vector<Point>& Vertices);
+
+    void Release(std::vector<Scene>& Scenes, const int& ID);
+};
+
+// reference src/PatchMatch.cpp:506-638, in memory: results go to Scenes[ID].depth/normal/cost.
+// `results` (optional) receives the outputs without touching Scenes[ID], which is
+// what a Jacobi pass over many Problems needs.
+struct ProblemResult {
+    Image depth, normal, cost;
+};
+void ProcessProblem(std::vector<Scene>& Scenes, const int ID, bool geom_consistency, bool planar_prior,
+                    uint64_t seed = 0, int device = 0, int max_scale = 2, ProblemResult* results = nullptr);
+
+// ---- planar prior construction (planar_prior.cpp), usable without a device ----
+namespace mpmvs_host {
+// reference src/PatchMatch.cpp:782-853
+void TriangulateVertices(int width, int height, const float* costs, const float* geom_costs, bool geomPlanarPrior,
+                         std::vector<Point>& Vertices);
+// reference src/PatchMatch.cpp:757-780 (cv::Subdiv2D replaced by an exact incremental Delaunay)
+std::vector<Triangle> Delaunay(const Rect boundRC, const std::vector<Point>& points);
+// reference src/PatchMatch.cpp:723-755 (cv::SVD::solveZ of three points = the plane through them)
+float4 PriorPlane(const Camera& cam, const Triangle& t, const float4* planes, int width);
+// reference src/PatchMatch.cpp:554-595: rasterise the triangles into a label mask, fit planes,
+// drop pixels whose prior depth leaves [depth_min, depth_max]
+void BuildPrior(const Camera& cam, int width, int height, const std::vector<Triangle>& triangles, const float4* planes,
+                float depth_min, float depth_max, std::vector<float4>& planeParams, Image& mask);
+}  // namespace mpmvs_host
+
+#endif

@@ -1,0 +1,333 @@
+// PatchMatchHost.cpp -- the host half of PatchMatchCUDA and ProcessProblem()
+// (reference src/PatchMatch.cpp:506-721, :855-1139) re-pointed at the C ABI of
+// include/mpmvs.h.  Error convention of the reference is kept here: print and
+// exit(EXIT_FAILURE) (reference src/PatchMatch.cpp:60-65); the C ABI underneath
+// never exits.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+
+#include "PatchMatch.h"
+
+void PatchMatchCUDA::check(int rc, const char* what) {
+    if (rc != 0) {
+        std::cerr << what << " failed (" << rc << "): " << mpmvs_last_error(ctx) << std::endl;
+        exit(EXIT_FAILURE);
+    }
+}
+
+PatchMatchCUDA::~PatchMatchCUDA() {
+    if (ctx) mpmvs_destroy(ctx);
+    ctx = nullptr;
+}
+
+// reference src/PatchMatch.cpp:655-665
+void PatchMatchCUDA::SetGeomConsistencyParams(bool geom_consistency, bool planar_prior) {
+    params.geom_consistency = geom_consistency;
+    if (geom_consistency) {
+        params.max_iterations = 2;
+        params.geomPlanarPrior = planar_prior;
+    } else {
+        params.max_iterations = 3;
+    }
+}
+// reference src/PatchMatch.cpp:667-670
+void PatchMatchCUDA::SetPlanarPriorParams() { params.planar_prior = true; }
+void PatchMatchCUDA::SetFolder(const std::string& in, const std::string& out) {
+    input_folder = in;
+    output_folder = out;
+}
+
+// reference src/PatchMatch.cpp:863-958, minus file reading and rescaling
+void PatchMatchCUDA::PatchMatchInit(std::vector<Scene>& Scenes, const int ID) {
+    images.clear();
+    depths.clear();
+    cameras.clear();
+    std::vector<int>& srcID = Scenes[ID].srcID;
+    num_img = (int)srcID.size();
+    for (int i = 0; i < num_img; ++i) {
+        Scene& s = Scenes[srcID[i]];
+        if (s.image.empty()) {
+            std::cout << "Can not read this image !" << srcID[i] << std::endl;
+            exit(EXIT_FAILURE);
+        }
+        images.push_back(&s.image);
+        Camera cam = s.cam;
+        cam.height = s.image.rows;
+        cam.width = s.image.cols;
+        cameras.push_back(cam);
+    }
+    params.depth_min = cameras[0].depth_min * 0.6f;  // reference :929-930
+    params.depth_max = cameras[0].depth_max * 1.2f;
+    params.num_images = num_img;
+    if (params.geom_consistency) {
+        for (int i = 1; i < num_img; ++i) {
+            const Scene& s = Scenes[srcID[i]];
+            if (s.depth.empty()) {
+                std::cout << "Can not read this depth image !" << std::endl;
+                exit(EXIT_FAILURE);
+            }
+            depths.push_back(s.depth);
+        }
+    }
+}
+
+// reference src/PatchMatch.cpp:960-976
+void PatchMatchCUDA::AllocatePatchMatch() {
+    const size_t wh = (size_t)cameras[0].width * cameras[0].height;
+    if (!ctx) ctx = mpmvs_create(device);
+    if (!ctx) {
+        std::cerr << "mpmvs_create failed: " << mpmvs_last_error(nullptr) << std::endl;
+        exit(EXIT_FAILURE);
+    }
+    hostPlaneHypotheses.assign(wh, float4{0, 0, 0, 0});
+    hostCosts.assign(wh, 0.0f);
+    if (params.geom_consistency) hostGeomCosts.assign(wh, 0.0f);
+}
+
+// reference src/PatchMatch.cpp:998-1089
+void PatchMatchCUDA::CudaMemInit(Scene& scene) {
+    std::vector<const float*> ptrs;
+    std::vector<size_t> pitches;
+    for (int i = 0; i < num_img; ++i) {
+        ptrs.push_back(images[i]->data.data());
+        pitches.push_back((size_t)images[i]->cols * sizeof(float));
+    }
+    check(mpmvs_set_views(ctx, num_img, cameras.data(), ptrs.data(), pitches.data()), "mpmvs_set_views");
+    if (params.geom_consistency) {
+        std::vector<const float*> dptr;
+        std::vector<int> ws, hs;
+        for (const Image& d : depths) {
+            dptr.push_back(d.data.data());
+            ws.push_back(d.cols);
+            hs.push_back(d.rows);
+        }
+        check(mpmvs_set_src_depths(ctx, num_img - 1, dptr.data(), ws.data(), hs.data(), nullptr), "mpmvs_set_src_depths");
+        // previous result of this image is the start state (reference :1052-1086)
+        if (scene.depth.empty() || scene.normal.empty() || scene.cost.empty()) {
+            std::cout << "Can not read this depth image !" << std::endl;
+            exit(0);
+        }
+        const int width = scene.depth.cols, height = scene.depth.rows;
+        for (int row = 0; row < height; ++row)
+            for (int col = 0; col < width; ++col) {
+                const size_t idx = (size_t)row * width + col;
+                hostPlaneHypotheses[idx] = float4{scene.normal.at(row, col, 0), scene.normal.at(row, col, 1), scene.normal.at(row, col, 2), scene.depth.at(row, col)};
+                hostCosts[idx] = scene.cost.at(row, col);
+            }
+        check(mpmvs_set_state(ctx, hostPlaneHypotheses.data(), hostCosts.data()), "mpmvs_set_state");
+    }
+}
+
+// reference src/PatchMatch.cpp:978-996
+void PatchMatchCUDA::CudaPlanarPriorInitialization(const std::vector<float4>& PlaneParams, const Image& masks) {
+    const int W = cameras[0].width, H = cameras[0].height;
+    hostPriorPlanes.assign((size_t)W * H, float4{0, 0, 0, 0});
+    hostPlaneMask.assign((size_t)W * H, 0u);
+    for (int i = 0; i < H; ++i)
+        for (int j = 0; j < W; ++j) {
+            const size_t idx = (size_t)i * W + j;
+            hostPlaneMask[idx] = (unsigned int)masks.at(i, j);
+            if (masks.at(i, j) > 0) hostPriorPlanes[idx] = PlaneParams[(size_t)masks.at(i, j) - 1];
+        }
+    check(mpmvs_set_prior(ctx, hostPriorPlanes.data(), hostPlaneMask.data()), "mpmvs_set_prior");
+}
+
+// reference src/PatchMatch.cu:1188-1254: the launches live behind mpmvs_run, the
+// device-to-host copies (:1246-1251) behind mpmvs_get
+void PatchMatchCUDA::Run() {
+    check(mpmvs_run(ctx, &params, seed), "mpmvs_run");
+    check(mpmvs_get(ctx, hostPlaneHypotheses.data(), hostCosts.data(), params.geomPlanarPrior && !hostGeomCosts.empty() ? hostGeomCosts.data() : nullptr), "mpmvs_get");
+}
+
+float PatchMatchCUDA::GetDepthFromPlaneParam(const float4 pl, const int x, const int y) {
+    const Camera& c = cameras[0];
+    return -pl.w * c.K[0] / (((float)x - c.K[2]) * pl.x + (c.K[0] / c.K[4]) * ((float)y - c.K[5]) * pl.y + c.K[0] * pl.z);
+}
+float PatchMatchCUDA::GetMinDepth() { return params.depth_min; }
+float PatchMatchCUDA::GetMaxDepth() { return params.depth_max; }
+int PatchMatchCUDA::GetReferenceImageWidth() { return cameras[0].width; }
+int PatchMatchCUDA::GetReferenceImageHeight() { return cameras[0].height; }
+const Image& PatchMatchCUDA::GetReferenceImage() { return *images[0]; }
+float4 PatchMatchCUDA::GetPlaneHypothesis(const int index) { return hostPlaneHypotheses[index]; }
+float PatchMatchCUDA::GetCost(const int index) { return hostCosts[index]; }
+float PatchMatchCUDA::GetGeomCost(const int index) { return hostGeomCosts[index]; }
+
+float4 PatchMatchCUDA::GetPriorPlaneParams(const Triangle triangle, int width) {
+    return mpmvs_host::PriorPlane(cameras[0], triangle, hostPlaneHypotheses.data(), width);
+}
+std::vector<Triangle> PatchMatchCUDA::DelaunayTriangulation(const Rect boundRC, const std::vector<Point>& points) {
+    if (points.empty()) {
+        std::cout << "No Point to Triangulate!" << std::endl;
+        exit(1);
+    }
+    return mpmvs_host::Delaunay(boundRC, points);
+}
+void PatchMatchCUDA::GetTriangulateVertices(std::vector<Point>& Vertices) {
+    mpmvs_host::TriangulateVertices(GetReferenceImageWidth(), GetReferenceImageHeight(), hostCosts.data(),
+                                    params.geomPlanarPrior ? hostGeomCosts.data() : nullptr, params.geomPlanarPrior, Vertices);
+}
+
+// reference src/PatchMatch.cpp:1091-1139
+void PatchMatchCUDA::Release(std::vector<Scene>&, const int&) {
+    hostPlaneHypotheses.clear();
+    hostCosts.clear();
+    hostGeomCosts.clear();
+    hostPriorPlanes.clear();
+    hostPlaneMask.clear();
+    if (ctx) mpmvs_destroy(ctx);
+    ctx = nullptr;
+}
+
+// reference src/PatchMatch.cpp:506-638
+void ProcessProblem(std::vector<Scene>& Scenes, const int ID, bool geom_consistency, bool planar_prior, uint64_t seed,
+                    int device, int max_scale, ProblemResult* results) {
+    Scene& scene = Scenes[ID];
+    PatchMatchCUDA MP;
+    MP.SetDevice(device);
+    MP.SetSeed(seed);
+    MP.SetMaxScale(max_scale);
+    MP.SetGeomConsistencyParams(geom_consistency, planar_prior);
+    MP.PatchMatchInit(Scenes, ID);
+    MP.AllocatePatchMatch();
+    MP.CudaMemInit(Scenes[ID]);
+    MP.Run();
+
+    const int width = MP.GetReferenceImageWidth();
+    const int height = MP.GetReferenceImageHeight();
+
+    if (planar_prior) {
+        MP.SetPlanarPriorParams();
+        MP.SetGeomConsistencyParams(false, true);
+        const Rect imageRC{0, 0, width, height};
+        std::vector<Point> Vertices;
+        MP.GetTriangulateVertices(Vertices);
+        const auto triangles = MP.DelaunayTriangulation(imageRC, Vertices);
+        Image mask_tri;
+        std::vector<float4> planeParams_tri;
+        std::vector<float4> planes((size_t)width * height);
+        for (size_t i = 0; i < planes.size(); ++i) planes[i] = MP.GetPlaneHypothesis((int)i);
+        mpmvs_host::BuildPrior(MP.GetReferenceCamera(), width, height, triangles, planes.data(), MP.GetMinDepth(), MP.GetMaxDepth(),
+                               planeParams_tri, mask_tri);
+        MP.CudaPlanarPriorInitialization(planeParams_tri, mask_tri);
+        MP.SetSeed(seed + 0x9E3779B97F4A7C15ull);  // second Run(): its own RNG streams
+        MP.Run();
+        MP.SetGeomConsistencyParams(geom_consistency, planar_prior);
+    }
+
+    ProblemResult local;
+    ProblemResult& out = results ? *results : local;
+    out.depth = Image(height, width, 1);
+    out.normal = Image(height, width, 3);
+    out.cost = Image(height, width, 1);
+    for (int row = 0; row < height; ++row)
+        for (int col = 0; col < width; ++col) {
+            const int idx = row * width + col;
+            const float4 pl = MP.GetPlaneHypothesis(idx);
+            out.depth.at(row, col) = pl.w;
+            out.normal.at(row, col, 0) = pl.x;
+            out.normal.at(row, col, 1) = pl.y;
+            out.normal.at(row, col, 2) = pl.z;
+            out.cost.at(row, col) = MP.GetCost(idx);
+        }
+    if (!results) {
+        scene.depth = out.depth;
+        scene.normal = out.normal;
+        scene.cost = out.cost;
+    }
+    MP.Release(Scenes, ID);
+}
+
+// ---------------------------------------------------------------------------
+// C entry points used by the Python tests / bench (ctypes)
+// ---------------------------------------------------------------------------
+extern "C" {
+
+// vertices -> out_xy (2 ints each); returns the count (may exceed cap: call again)
+int mpmvs_host_triangulate_vertices(int w, int h, const float* costs, const float* geom_costs, int geomPlanarPrior, int* out_xy, int cap) {
+    std::vector<Point> v;
+    mpmvs_host::TriangulateVertices(w, h, costs, geom_costs, geomPlanarPrior != 0, v);
+    for (size_t i = 0; i < v.size() && (int)i < cap; ++i) {
+        out_xy[2 * i] = v[i].x;
+        out_xy[2 * i + 1] = v[i].y;
+    }
+    return (int)v.size();
+}
+
+// triangles -> out_xy (6 ints each); returns the count
+int mpmvs_host_delaunay(int w, int h, const int* xy, int n, int* out_xy, int cap) {
+    std::vector<Point> pts;
+    for (int i = 0; i < n; ++i) pts.push_back(Point(xy[2 * i], xy[2 * i + 1]));
+    const auto tris = mpmvs_host::Delaunay(Rect{0, 0, w, h}, pts);
+    for (size_t i = 0; i < tris.size() && (int)i < cap; ++i) {
+        out_xy[6 * i + 0] = tris[i].pt1.x;
+        out_xy[6 * i + 1] = tris[i].pt1.y;
+        out_xy[6 * i + 2] = tris[i].pt2.x;
+        out_xy[6 * i + 3] = tris[i].pt2.y;
+        out_xy[6 * i + 4] = tris[i].pt3.x;
+        out_xy[6 * i + 5] = tris[i].pt3.y;
+    }
+    return (int)tris.size();
+}
+
+// the whole host prior construction of ProcessProblem (reference src/PatchMatch.cpp:532-604)
+// from a finished Run(): planes = (world normal, depth) float4, costs, geom costs ->
+// per-pixel prior planes (float4) + mask (u32), as CudaPlanarPriorInitialization uploads them.
+// Returns the number of triangles used, or -1.
+int mpmvs_host_build_prior(const mpmvs_camera* cam, int w, int h, const float* planes4, const float* costs, const float* geom_costs,
+                           int geomPlanarPrior, float depth_min, float depth_max, float* prior4, uint32_t* mask) {
+    std::vector<Point> v;
+    mpmvs_host::TriangulateVertices(w, h, costs, geom_costs, geomPlanarPrior != 0, v);
+    if (v.empty()) return -1;
+    const auto tris = mpmvs_host::Delaunay(Rect{0, 0, w, h}, v);
+    std::vector<float4> pp;
+    Image m;
+    mpmvs_host::BuildPrior(*cam, w, h, tris, (const float4*)planes4, depth_min, depth_max, pp, m);
+    for (int i = 0; i < h; ++i)
+        for (int j = 0; j < w; ++j) {
+            const size_t idx = (size_t)i * w + j;
+            mask[idx] = (uint32_t)m.at(i, j);
+            float4 o{0, 0, 0, 0};
+            if (m.at(i, j) > 0) o = pp[(size_t)m.at(i, j) - 1];
+            std::memcpy(prior4 + 4 * idx, &o, 16);
+        }
+    return (int)pp.size();
+}
+
+// One Problem through the reference's pass schedule (src/main.cpp:20-41) with the
+// source depth maps held fixed (SURVEY 8d cfg 2/3): photometric pass, then
+// geom_iterations geometric passes, with the planar-prior re-run where the
+// reference schedules it.  images[0]/cams[0] is the reference view.
+int mpmvs_host_run_pipeline(int device, int n, const mpmvs_camera* cams, const float* const* images, int max_scale,
+                            int geom_iterations, int planar_prior, int geomPlanarPrior, uint64_t seed,
+                            const float* const* src_depths, float* out_depth, float* out_normal3, float* out_cost) {
+    std::vector<Scene> Scenes(n);
+    for (int i = 0; i < n; ++i) {
+        Scene& s = Scenes[i];
+        s.refID = i;
+        s.cam = cams[i];
+        s.image = Image(cams[i].height, cams[i].width, 1);
+        std::memcpy(s.image.data.data(), images[i], s.image.data.size() * sizeof(float));
+        if (i > 0 && src_depths) {
+            s.depth = Image(cams[i].height, cams[i].width, 1);
+            std::memcpy(s.depth.data.data(), src_depths[i - 1], s.depth.data.size() * sizeof(float));
+        }
+    }
+    Scenes[0].estimate = true;
+    for (int i = 0; i < n; ++i) Scenes[0].srcID.push_back(i);
+    bool pp = !geomPlanarPrior && planar_prior;  // reference src/main.cpp:20
+    ProcessProblem(Scenes, 0, false, pp, seed, device, max_scale);
+    for (int g = 0; g < geom_iterations; ++g) {
+        pp = (geomPlanarPrior && g != geom_iterations - 1);  // reference src/main.cpp:31-34
+        ProcessProblem(Scenes, 0, true, pp, seed + 1 + (uint64_t)g, device, max_scale);
+    }
+    const Scene& r = Scenes[0];
+    std::memcpy(out_depth, r.depth.data.data(), r.depth.data.size() * sizeof(float));
+    std::memcpy(out_normal3, r.normal.data.data(), r.normal.data.size() * sizeof(float));
+    std::memcpy(out_cost, r.cost.data.data(), r.cost.data.size() * sizeof(float));
+    return 0;
+}
+}  // extern "C"

@@ -1,0 +1,298 @@
+// planar_prior.cpp -- host construction of the planar prior that feeds the
+// second Run() of a Problem:
+//   vertices   reference src/PatchMatch.cpp:782-853  GetTriangulateVertices
+//   Delaunay   reference src/PatchMatch.cpp:757-780  (cv::Subdiv2D there)
+//   plane fit  reference src/PatchMatch.cpp:723-755  (cv::SVD::solveZ there)
+//   raster     reference src/PatchMatch.cpp:554-595
+// OpenCV is absent from the target image, so the triangulation is an own
+// incremental Bowyer-Watson with exact integer predicates, and the 3-point
+// null-space solve is the closed form (cross product).  Parity note: for point
+// sets with four or more cocircular points (common on a pixel grid) the Delaunay
+// triangulation is not unique and cv::Subdiv2D's choice, as well as its triangle
+// ORDER (which decides which triangle owns a shared border pixel), cannot be
+// reproduced without OpenCV: this file is "parity unpinned" against the
+// reference on those two points and pinned by its own property tests.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "PatchMatch.h"
+
+namespace mpmvs_host {
+
+// ---------------------------------------------------------------------------
+// vertices: per 5x5 cell, the pixel(s) with the most reliable depth
+// ---------------------------------------------------------------------------
+void TriangulateVertices(int width, int height, const float* costs, const float* geom_costs, bool geomPlanarPrior,
+                         std::vector<Point>& Vertices) {
+    Vertices.clear();
+    const int step_size = 5;
+    for (int row = 0; row < height; row += step_size) {
+        for (int col = 0; col < width; col += step_size) {
+            const int c_bound = std::min(width, col + step_size);
+            const int r_bound = std::min(height, row + step_size);
+            if (!geomPlanarPrior) {
+                float min_cost = 2.0f;
+                Point best;
+                for (int r = row; r < r_bound; ++r)
+                    for (int c = col; c < c_bound; ++c) {
+                        const float cost = costs[(size_t)r * width + c];
+                        if (cost < 2.0f && min_cost > cost) {
+                            best = Point(c, r);
+                            min_cost = cost;
+                        }
+                    }
+                if (min_cost < 0.1f) Vertices.push_back(best);
+            } else {
+                float minCosts[3] = {2.0f, 2.0f, 2.0f};
+                Point pts[3];
+                float cost_sum = 0.0f;
+                for (int r = row; r < r_bound; ++r)
+                    for (int c = col; c < c_bound; ++c) {
+                        const size_t idx = (size_t)r * width + c;
+                        const float cost = costs[idx];
+                        cost_sum += cost;
+                        if (cost < 1.0f && geom_costs[idx] < 0.4f && cost < minCosts[2]) {
+                            minCosts[2] = cost;
+                            pts[2] = Point(c, r);
+                            for (int i = 1; i >= 0; --i) {
+                                if (minCosts[i] <= minCosts[i + 1]) break;
+                                std::swap(minCosts[i], minCosts[i + 1]);
+                                std::swap(pts[i], pts[i + 1]);
+                            }
+                        }
+                    }
+                // the divisor is the product of the absolute bounds, not the cell
+                // area (reference src/PatchMatch.cpp:841, kept as is)
+                cost_sum = (float)(cost_sum / (float)(r_bound * c_bound) * 0.85);
+                const float thresh_cost = std::max(cost_sum, 0.2f);
+                for (int i = 0; i < 3; ++i) {
+                    if (minCosts[i] < thresh_cost)
+                        Vertices.push_back(pts[i]);
+                    else
+                        break;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Delaunay triangulation: incremental Bowyer-Watson, exact 128-bit predicates
+// ---------------------------------------------------------------------------
+namespace {
+typedef __int128 i128;
+
+struct Tri {
+    int v[3];  // counter-clockwise
+    int n[3];  // n[i]: neighbour across the edge opposite v[i]
+};
+
+struct Mesh {
+    std::vector<long long> px, py;
+    std::vector<Tri> tris;
+    std::vector<char> dead;
+    int last = 0;
+
+    i128 orient(int a, int b, int c) const {
+        return (i128)(px[b] - px[a]) * (py[c] - py[a]) - (i128)(py[b] - py[a]) * (px[c] - px[a]);
+    }
+    // > 0: d strictly inside the circumcircle of counter-clockwise (a, b, c)
+    i128 incircle(int a, int b, int c, int d) const {
+        const i128 ax = px[a] - px[d], ay = py[a] - py[d];
+        const i128 bx = px[b] - px[d], by = py[b] - py[d];
+        const i128 cx = px[c] - px[d], cy = py[c] - py[d];
+        const i128 a2 = ax * ax + ay * ay, b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
+        return ax * (by * c2 - b2 * cy) - ay * (bx * c2 - b2 * cx) + a2 * (bx * cy - by * cx);
+    }
+    int locate(int p) {
+        int t = last;
+        for (size_t guard = 0; guard < tris.size() * 3 + 16; ++guard) {
+            bool moved = false;
+            for (int i = 0; i < 3; ++i) {
+                const int a = tris[t].v[(i + 1) % 3], b = tris[t].v[(i + 2) % 3];
+                if (orient(a, b, p) < 0) {
+                    t = tris[t].n[i];
+                    moved = true;
+                    break;
+                }
+            }
+            if (!moved) return t;
+        }
+        return t;
+    }
+    bool insert(int p) {
+        const int t0 = locate(p);
+        for (int i = 0; i < 3; ++i)
+            if (px[tris[t0].v[i]] == px[p] && py[tris[t0].v[i]] == py[p]) return false;  // duplicate point
+        // cavity = connected set of triangles whose circumcircle strictly contains p
+        std::vector<int> cavity, stack;
+        std::vector<int> mark_list;
+        stack.push_back(t0);
+        dead[t0] = 2;
+        while (!stack.empty()) {
+            const int t = stack.back();
+            stack.pop_back();
+            cavity.push_back(t);
+            for (int i = 0; i < 3; ++i) {
+                const int nb = tris[t].n[i];
+                if (nb < 0 || dead[nb]) continue;
+                if (incircle(tris[nb].v[0], tris[nb].v[1], tris[nb].v[2], p) > 0) {
+                    dead[nb] = 2;
+                    stack.push_back(nb);
+                }
+            }
+        }
+        struct Edge {
+            int a, b, outer, tri;
+        };
+        std::vector<Edge> edges;
+        for (int t : cavity)
+            for (int i = 0; i < 3; ++i) {
+                const int nb = tris[t].n[i];
+                if (nb >= 0 && dead[nb] == 2) continue;
+                Edge e;
+                e.a = tris[t].v[(i + 1) % 3];
+                e.b = tris[t].v[(i + 2) % 3];
+                e.outer = nb;
+                e.tri = -1;
+                edges.push_back(e);
+                // remember which cavity triangle the outer neighbour pointed to
+                if (nb >= 0)
+                    for (int j = 0; j < 3; ++j)
+                        if (tris[nb].n[j] == t) tris[nb].n[j] = -2 - (int)(edges.size() - 1);
+            }
+        for (int t : cavity) dead[t] = 1;
+        for (Edge& e : edges) {
+            Tri nt;
+            nt.v[0] = p;
+            nt.v[1] = e.a;
+            nt.v[2] = e.b;
+            nt.n[0] = e.outer;
+            nt.n[1] = nt.n[2] = -1;
+            e.tri = (int)tris.size();
+            tris.push_back(nt);
+            dead.push_back(0);
+        }
+        for (size_t k = 0; k < edges.size(); ++k) {
+            const Edge& e = edges[k];
+            if (e.outer >= 0)
+                for (int j = 0; j < 3; ++j)
+                    if (tris[e.outer].n[j] == -2 - (int)k) tris[e.outer].n[j] = e.tri;
+            for (const Edge& f : edges) {
+                if (f.a == e.b) tris[e.tri].n[1] = f.tri;  // across edge (b, p)
+                if (f.b == e.a) tris[e.tri].n[2] = f.tri;  // across edge (p, a)
+            }
+        }
+        last = edges.empty() ? last : edges[0].tri;
+        return true;
+    }
+};
+}  // namespace
+
+std::vector<Triangle> Delaunay(const Rect boundRC, const std::vector<Point>& points) {
+    std::vector<Triangle> results;
+    if (points.empty()) return results;
+    Mesh m;
+    const long long K = 1LL << 24;  // super triangle far outside any image (exactness: |coord| < 2^26)
+    (void)boundRC;
+    m.px = {-K, 3 * K, -K};
+    m.py = {-K, -K, 3 * K};
+    Tri t0;
+    t0.v[0] = 0;
+    t0.v[1] = 1;
+    t0.v[2] = 2;
+    t0.n[0] = t0.n[1] = t0.n[2] = -1;
+    m.tris.push_back(t0);
+    m.dead.push_back(0);
+    for (const Point& p : points) {
+        m.px.push_back(p.x);
+        m.py.push_back(p.y);
+        m.insert((int)m.px.size() - 1);
+    }
+    for (size_t t = 0; t < m.tris.size(); ++t) {
+        if (m.dead[t]) continue;
+        const Tri& T = m.tris[t];
+        if (T.v[0] < 3 || T.v[1] < 3 || T.v[2] < 3) continue;  // touches the super triangle
+        results.push_back(Triangle(Point((int)m.px[T.v[0]], (int)m.py[T.v[0]]), Point((int)m.px[T.v[1]], (int)m.py[T.v[1]]),
+                                   Point((int)m.px[T.v[2]], (int)m.py[T.v[2]])));
+    }
+    return results;
+}
+
+// ---------------------------------------------------------------------------
+// plane through the three back-projected triangle vertices
+// ---------------------------------------------------------------------------
+static void point_on_ref_cam(const Camera& cam, int x, int y, float depth, double X[3]) {
+    // reference src/PatchMatch.cpp:200-209 (Get3DPointonRefCam), fp32 there
+    X[0] = (double)(depth * ((float)x - cam.K[2]) / cam.K[0]);
+    X[1] = (double)(depth * ((float)y - cam.K[5]) / cam.K[4]);
+    X[2] = (double)depth;
+}
+
+float4 PriorPlane(const Camera& cam, const Triangle& t, const float4* planes, int width) {
+    double X1[3], X2[3], X3[3];
+    point_on_ref_cam(cam, t.pt1.x, t.pt1.y, planes[(size_t)t.pt1.y * width + t.pt1.x].w, X1);
+    point_on_ref_cam(cam, t.pt2.x, t.pt2.y, planes[(size_t)t.pt2.y * width + t.pt2.x].w, X2);
+    point_on_ref_cam(cam, t.pt3.x, t.pt3.y, planes[(size_t)t.pt3.y * width + t.pt3.x].w, X3);
+    const double u[3] = {X2[0] - X1[0], X2[1] - X1[1], X2[2] - X1[2]};
+    const double v[3] = {X3[0] - X1[0], X3[1] - X1[1], X3[2] - X1[2]};
+    double n[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+    double norm = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    if (!(norm > 1e-30)) {  // collinear points: no unique plane; take the fronto-parallel one
+        n[0] = 0.0;
+        n[1] = 0.0;
+        n[2] = -1.0;
+        norm = 1.0;
+    }
+    double d = -(n[0] * X1[0] + n[1] * X1[1] + n[2] * X1[2]);
+    if (d < 0) norm = -norm;  // reference src/PatchMatch.cpp:746-752: offset made positive
+    float4 o;
+    o.x = (float)(n[0] / norm);
+    o.y = (float)(n[1] / norm);
+    o.z = (float)(n[2] / norm);
+    o.w = (float)(d / norm);
+    return o;
+}
+
+static float depth_from_plane(const Camera& cam, const float4 pl, int x, int y) {
+    // reference src/PatchMatch.cpp:650-653
+    return -pl.w * cam.K[0] / (((float)x - cam.K[2]) * pl.x + (cam.K[0] / cam.K[4]) * ((float)y - cam.K[5]) * pl.y + cam.K[0] * pl.z);
+}
+
+void BuildPrior(const Camera& cam, int width, int height, const std::vector<Triangle>& triangles, const float4* planes,
+                float depth_min, float depth_max, std::vector<float4>& planeParams, Image& mask) {
+    const Rect imageRC{0, 0, width, height};
+    mask = Image(height, width, 1, 0.0f);
+    planeParams.clear();
+    uint32_t idx = 0;
+    for (const Triangle& t : triangles) {
+        if (!(imageRC.contains(t.pt1) && imageRC.contains(t.pt2) && imageRC.contains(t.pt3))) continue;
+        const float L01 = (float)std::sqrt(std::pow(t.pt1.x - t.pt2.x, 2) + std::pow(t.pt1.y - t.pt2.y, 2));
+        const float L02 = (float)std::sqrt(std::pow(t.pt1.x - t.pt3.x, 2) + std::pow(t.pt1.y - t.pt3.y, 2));
+        const float L12 = (float)std::sqrt(std::pow(t.pt2.x - t.pt3.x, 2) + std::pow(t.pt2.y - t.pt3.y, 2));
+        const float max_edge = std::max(L01, std::max(L02, L12));
+        const float step = (float)(1.0 / max_edge);
+        // barycentric stepping of the reference (src/PatchMatch.cpp:564-570)
+        for (float p = 0; p < 1.0; p += step) {
+            for (float q = 0; q < 1.0 - p; q += step) {
+                const int x = (int)((double)(p * (float)t.pt1.x + q * (float)t.pt2.x) + (1.0 - p - q) * t.pt3.x);
+                const int y = (int)((double)(p * (float)t.pt1.y + q * (float)t.pt2.y) + (1.0 - p - q) * t.pt3.y);
+                if (x >= 0 && y >= 0 && x < width && y < height) mask.at(y, x) = (float)(idx + 1.0);
+            }
+            if (!(step > 0.0f) || !std::isfinite(step)) break;  // degenerate triangle: one sample
+        }
+        planeParams.push_back(PriorPlane(cam, t, planes, width));
+        ++idx;
+    }
+    for (int j = 0; j < height; ++j)
+        for (int i = 0; i < width; ++i)
+            if (mask.at(j, i) > 0) {
+                const float4 n4 = planeParams[(size_t)mask.at(j, i) - 1];
+                const float d = depth_from_plane(cam, n4, i, j);
+                if (!(d <= depth_max && d >= depth_min)) mask.at(j, i) = 0;
+            }
+}
+
+}  // namespace mpmvs_host

@@ -1,0 +1,143 @@
+"""Problem-level multi-GPU schedule.
+
+The reference processes its Problems (one per reference image) strictly one
+after the other on device 0 and exchanges depth maps through depths.dmb files
+(reference src/main.cpp:20-41, src/PatchMatch.cpp:620-633 -> :941-948).  Here:
+
+  * Problems are dealt round-robin to the ranks (one process per GPU); each
+    owned Problem keeps its context -- images, planes, costs -- resident in HBM
+    across all passes (about 0.3 GB per 1600x1200 Problem);
+  * within a pass Problems are independent, so there is no data-path collective;
+  * between passes every Problem's new depth map must be visible to the
+    Problems that list it as a source: ONE all-gather of H*W fp32 depth maps per
+    pass (RCCL over xGMI when the tensors are on GPUs), which is also the barrier;
+  * semantics are Jacobi at every world size -- pass k+1 reads only pass-k depth
+    maps -- so 1/2/4/8-GPU results are bit-identical (the reference's in-place
+    file order is Gauss-Seidel; deviation recorded in DESIGN.md section 7).
+"""
+import ctypes
+
+import numpy as np
+
+from . import hostlib
+from ._abi import PatchMatchParams
+from .synth import kernel_depth_range
+
+PRIOR_SEED_OFFSET = 0x9E3779B97F4A7C15
+
+
+def owned_problems(n_problems, rank, world):
+    return [i for i in range(n_problems) if i % world == rank]
+
+
+class SceneScheduler:
+    def __init__(self, cams, images, sources, make_handle, rank=0, world=1, dist=None, device_tensors=False, max_scale=2):
+        """cams/images: all views of the scene; sources[i]: source-view ids of Problem i;
+        make_handle(): a fresh PatchMatch handle (engine.create(local_rank) in production)."""
+        self.cams, self.images, self.sources = cams, images, sources
+        self.n = len(sources)
+        self.rank, self.world, self.dist = rank, world, dist
+        self.max_scale = max_scale
+        self.owned = owned_problems(self.n, rank, world)
+        self.per_rank = (self.n + world - 1) // world
+        self.H, self.W = images[0].shape
+        for im in images:
+            assert im.shape == (self.H, self.W), "the all-gather assumes equally sized depth maps"
+        self.device_tensors = device_tensors
+        self.handles = {}
+        for i in self.owned:
+            h = make_handle()
+            ids = [i] + list(sources[i])
+            h.set_views([cams[j] for j in ids], [images[j] for j in ids])
+            self.handles[i] = h
+        self.results = {}   # problem -> (planes HxWx4 [world normal, depth], costs, geom or None)
+        self.all_depths = None
+
+    # -- one Run() (+ optional planar-prior re-run) of one Problem -----------
+    def _params(self, i, geom, planar):
+        cam = self.cams[i]
+        dmin, dmax = kernel_depth_range(cam)
+        p = PatchMatchParams(num_images=1 + len(self.sources[i]), depth_min=float(dmin), depth_max=float(dmax), max_scale=self.max_scale)
+        p.geom_consistency = geom
+        p.max_iterations = 2 if geom else 3            # reference src/PatchMatch.cpp:655-665
+        p.geomPlanarPrior = bool(geom and planar)
+        return p
+
+    def _process(self, i, geom, planar, seed):
+        h = self.handles[i]
+        p = self._params(i, geom, planar)
+        if geom:
+            self._attach_source_depths(i, h)
+            planes, costs, _ = self.results[i]
+            h.set_state(planes, costs)
+        h.run(p, seed)
+        if planar:                                      # reference src/PatchMatch.cpp:532-607
+            planes, costs, g = h.get(geom=True)
+            geom_pp = bool(p.geomPlanarPrior)
+            cam = self.cams[i]
+            prior, mask, ntri = hostlib.build_prior(cam, planes, costs, g if geom_pp else None, geom_pp, p.depth_min, p.depth_max)
+            if ntri <= 0:
+                raise RuntimeError("No Point to Triangulate!")
+            h.set_prior(prior, mask)
+            p.planar_prior = True
+            p.geom_consistency = False
+            p.max_iterations = 3
+            h.run(p, (seed + PRIOR_SEED_OFFSET) & 0xFFFFFFFFFFFFFFFF)
+        planes, costs, g = h.get(geom=True)
+        return planes, costs, g
+
+    # -- exchange --------------------------------------------------------------
+    def _attach_source_depths(self, i, h):
+        srcs = self.sources[i]
+        if self.device_tensors:
+            base = self.all_depths.data_ptr()
+            stride = self.H * self.W * 4
+            h.set_src_depths_device([base + j * stride for j in srcs], [self.W] * len(srcs), [self.H] * len(srcs))
+        else:
+            h.set_src_depths([self.all_depths[j] for j in srcs])
+
+    def _exchange(self):
+        """all-gather of the depth maps of this pass; doubles as the pass barrier"""
+        if self.device_tensors:
+            import torch
+            mine = torch.zeros((self.per_rank, self.H, self.W), dtype=torch.float32, device="cuda")
+            for k, i in enumerate(self.owned):
+                self.handles[i].export_depth_device(mine[k].data_ptr())
+            if self.world > 1:
+                full = torch.empty((self.world * self.per_rank, self.H, self.W), dtype=torch.float32, device="cuda")
+                self.dist.all_gather_into_tensor(full, mine)
+            else:
+                full = mine
+            torch.cuda.synchronize()
+            # rank r's k-th slot holds Problem r + k * world
+            order = [(i % self.world) * self.per_rank + i // self.world for i in range(self.n)]
+            self.all_depths = full[order].contiguous()
+        else:
+            mine = np.zeros((self.per_rank, self.H, self.W), np.float32)
+            for k, i in enumerate(self.owned):
+                mine[k] = self.results[i][0][..., 3]
+            if self.world > 1:
+                import torch
+                t = torch.from_numpy(mine)
+                outs = [torch.empty_like(t) for _ in range(self.world)]
+                self.dist.all_gather(outs, t)
+                full = np.concatenate([o.numpy() for o in outs], 0)
+            else:
+                full = mine
+            order = [(i % self.world) * self.per_rank + i // self.world for i in range(self.n)]
+            self.all_depths = np.ascontiguousarray(full[order])
+
+    # -- the pass schedule of reference src/main.cpp:20-41 ----------------------
+    def run(self, geom_iterations=2, planar_prior=True, geom_planar_prior=True, seed=12345):
+        planar0 = (not geom_planar_prior) and planar_prior
+        for i in self.owned:
+            self.results[i] = self._process(i, False, planar0, seed + i)
+        self._exchange()
+        for g in range(geom_iterations):
+            planar = bool(geom_planar_prior and g != geom_iterations - 1)
+            new = {}
+            for i in self.owned:
+                new[i] = self._process(i, True, planar, seed + 100003 * (g + 1) + i)
+            self.results = new          # Jacobi: nothing of pass g was visible during pass g
+            self._exchange()
+        return self.results

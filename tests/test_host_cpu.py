@@ -1,0 +1,156 @@
+"""CPU tests of the host layer: C-ABI surface (symbols only, no compute without
+a GPU) and the planar-prior construction (vertices, Delaunay, plane fit, raster).
+
+OpenCV (cv::Subdiv2D, cv::SVD) is absent here and on the GPU box, so these pieces
+are "parity unpinned" against the reference; they are pinned by the
+properties a Delaunay triangulation and a 3-point plane must satisfy.
+"""
+import ctypes
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hostlib(pm):
+    import __graft_entry__ as g
+    if not os.path.exists(os.path.join(ROOT, "mp-mvs_amd", "host", "libmpmvs_host.so")):
+        g.build()
+    return importlib.import_module("mp-mvs_amd.hostlib")
+
+
+def test_c_abi_exports_every_declared_symbol(pm):
+    """every function include/mpmvs.h declares must be exported by the HIP library
+    (loading needs no GPU; nothing is called)"""
+    header = open(os.path.join(ROOT, "include", "mpmvs.h")).read()
+    declared = sorted(set(re.findall(r"\b(mpmvs_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 20
+    engine = importlib.import_module("mp-mvs_amd.engine")
+    lib, fns = engine.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/mpmvs.h but not exported"
+    for name in engine.ALL_SYMBOLS:
+        assert name in declared, f"{name} bound in Python but not declared in include/mpmvs.h"
+
+
+def test_abi_struct_layouts(pm):
+    assert ctypes.sizeof(pm.Camera) == 112 and ctypes.sizeof(pm.PatchMatchParams) == 56
+    assert pm.Camera.height.offset == 96 and pm.Camera.width.offset == 100  # height first (reference PatchMatch.h:42-43)
+    assert pm.PatchMatchParams.geom_consistency.offset == 52
+    p = pm.PatchMatchParams()
+    assert (p.max_iterations, p.top_k, p.max_scale, p.sigma_spatial, p.sigma_color) == (3, 4, 2, 5.0, 3.0)
+
+
+def test_host_library_symbols(hostlib):
+    lib = hostlib.load()
+    for s in hostlib.SYMBOLS:
+        assert hasattr(lib, s)
+
+
+def test_product_has_no_cpu_fallback(pm):
+    """creating a context without a HIP device must fail loudly"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    engine = importlib.import_module("mp-mvs_amd.engine")
+    with pytest.raises(RuntimeError, match="mpmvs_create failed"):
+        engine.create(0)
+
+
+# ---------------------------------------------------------------------------
+def _incircle(a, b, c, d):
+    m = np.array([[a[0] - d[0], a[1] - d[1], (a[0] - d[0]) ** 2 + (a[1] - d[1]) ** 2],
+                  [b[0] - d[0], b[1] - d[1], (b[0] - d[0]) ** 2 + (b[1] - d[1]) ** 2],
+                  [c[0] - d[0], c[1] - d[1], (c[0] - d[0]) ** 2 + (c[1] - d[1]) ** 2]], dtype=object)
+    return (m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0])
+            + m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]))
+
+
+def _orient(a, b, c):
+    return (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0])
+
+
+@pytest.mark.parametrize("n,seed", [(5, 0), (60, 1), (400, 2)])
+def test_delaunay_properties(hostlib, n, seed):
+    rng = np.random.default_rng(seed)
+    pts = np.unique(rng.integers(0, 200, size=(n, 2)), axis=0).astype(np.int32)
+    rng.shuffle(pts)
+    tris = hostlib.delaunay(200, 200, pts)
+    ptset = {tuple(p) for p in pts.tolist()}
+    area2 = 0
+    for t in tris.tolist():
+        a, b, c = [tuple(v) for v in t]
+        assert a in ptset and b in ptset and c in ptset
+        o = _orient(a, b, c)
+        assert o > 0, "counter-clockwise, non-degenerate"
+        area2 += o
+        for p in ptset:  # empty circumcircle (exact integer arithmetic)
+            if p not in (a, b, c):
+                assert _incircle(a, b, c, p) <= 0
+    from scipy.spatial import ConvexHull
+    hull = ConvexHull(pts.astype(float))
+    assert area2 == int(round(2 * hull.volume)), "the triangles tile the convex hull"
+    used = {tuple(v) for t in tris.tolist() for v in t}
+    assert used == ptset
+
+
+def test_delaunay_grid_points_and_duplicates(hostlib):
+    """cocircular grid points and a duplicated point: still a valid triangulation"""
+    xs, ys = np.meshgrid(np.arange(0, 50, 5), np.arange(0, 40, 5))
+    pts = np.stack([xs.ravel(), ys.ravel()], -1).astype(np.int32)
+    pts = np.concatenate([pts, pts[:3]])
+    tris = hostlib.delaunay(64, 64, pts)
+    area2 = sum(_orient(*[tuple(v) for v in t]) for t in tris.tolist())
+    assert area2 == 2 * 45 * 35
+    assert len(tris) == 2 * 9 * 7
+
+
+def test_triangulate_vertices(hostlib):
+    costs = np.full((23, 31), 1.5, np.float32)
+    costs[2, 3] = 0.05      # cell (0,0) -> vertex (3,2)
+    costs[7, 12] = 0.09     # cell (row 5.., col 10..)
+    costs[7, 13] = 0.02     # lower cost in the same cell wins
+    costs[12, 22] = 0.11    # above the 0.1 threshold: no vertex
+    costs[22, 30] = 0.01    # ragged last cell
+    v = hostlib.triangulate_vertices(costs)
+    assert sorted(map(tuple, v.tolist())) == [(3, 2), (13, 7), (30, 22)]
+    # geometric variant: up to three vertices per cell, cost < 1, geom cost < 0.4, below max(0.85*sum/(r*c), 0.2)
+    geom = np.full_like(costs, 0.1)
+    geom[7, 13] = 0.5
+    costs[:] = 1.5
+    costs[7, 12], costs[7, 13], costs[8, 11], costs[8, 12] = 0.09, 0.02, 0.15, 0.19
+    v = hostlib.triangulate_vertices(costs, geom, True)
+    assert [tuple(p) for p in v.tolist()] == [(12, 7), (11, 8), (12, 8)]
+
+
+def test_build_prior_recovers_a_plane(pm, hostlib):
+    """planes/costs of a perfectly reconstructed slanted plane -> every prior plane
+    equals it, the mask covers the triangulated interior"""
+    W, H = 80, 60
+    sc = pm.synth.make_scene(W, H, [(0, 0, 0)], rot_deg=0.0)
+    cam = sc.views[0].cam
+    n = np.array([0.2, -0.1, -1.0])
+    n /= np.linalg.norm(n)
+    d = 5.0  # n.X + d = 0
+    u, v = np.meshgrid(np.arange(W), np.arange(H))
+    ray = np.stack([(u - cam.K[2]) / cam.K[0], (v - cam.K[5]) / cam.K[4], np.ones_like(u, float)], -1)
+    depth = -d / (ray @ n)
+    planes = np.zeros((H, W, 4), np.float32)
+    planes[..., :3] = n
+    planes[..., 3] = depth
+    costs = np.full((H, W), 0.05, np.float32)
+    prior, mask, ntri = hostlib.build_prior(cam, planes, costs, None, False, 1.0, 20.0)
+    assert ntri > 100
+    inside = mask > 0
+    assert inside[5:-6, 5:-6].mean() > 0.98
+    assert np.allclose(prior[inside][:, :3], n, atol=2e-3)
+    assert np.allclose(prior[inside][:, 3], d, rtol=2e-3)
+    assert (prior[inside][:, 3] > 0).all()  # offset made positive (reference PatchMatch.cpp:746-752)
+    # a depth range that excludes the plane clears the mask (reference :583-595)
+    _, mask2, _ = hostlib.build_prior(cam, planes, costs, None, False, 10.0, 20.0)
+    assert mask2.max() == 0

@@ -1,0 +1,78 @@
+"""GPU parity of the layers above Run(): the C++ ProcessProblem pass schedule
+(reference src/main.cpp:20-41 + src/PatchMatch.cpp:506-638) with the host-built
+planar prior, and the multi-Problem scheduler with device-resident depth-map
+exchange -- each against the same schedule driven on the CPU oracle."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PRIOR_SEED_OFFSET = 0x9E3779B97F4A7C15
+
+
+def oracle_pipeline(pm, oracle, hostlib, cams, imgs, src_depths, max_scale, geom_iterations, planar_prior, geom_pp, seed):
+    """the schedule of mpmvs_host_run_pipeline on the oracle"""
+    h = oracle.create()
+    h.set_views(cams, imgs)
+    dmin, dmax = pm.synth.kernel_depth_range(cams[0])
+    state = {}
+
+    def process(geom, planar, sd):
+        p = pm.PatchMatchParams(num_images=len(cams), depth_min=float(dmin), depth_max=float(dmax), max_scale=max_scale)
+        p.geom_consistency = geom
+        p.max_iterations = 2 if geom else 3
+        p.geomPlanarPrior = bool(geom and planar)
+        if geom:
+            h.set_src_depths(src_depths)
+            h.set_state(state["planes"], state["costs"])
+        h.run(p, sd)
+        if planar:
+            planes, costs, g = h.get(geom=True)
+            gpp = bool(p.geomPlanarPrior)
+            prior, mask, ntri = hostlib.build_prior(cams[0], planes, costs, g if gpp else None, gpp, p.depth_min, p.depth_max)
+            assert ntri > 0
+            h.set_prior(prior, mask)
+            p.planar_prior = True
+            p.geom_consistency = False
+            p.max_iterations = 3
+            h.run(p, (sd + PRIOR_SEED_OFFSET) & 0xFFFFFFFFFFFFFFFF)
+        state["planes"], state["costs"] = h.get()
+
+    process(False, (not geom_pp) and planar_prior, seed)
+    for g in range(geom_iterations):
+        process(True, geom_pp and g != geom_iterations - 1, seed + 1 + g)
+    return state["planes"], state["costs"]
+
+
+@pytest.mark.parametrize("geom_iterations,planar_prior,geom_pp,max_scale", [(1, False, False, 2),   # cfg 2
+                                                                           (2, True, True, 2),      # cfg 3 (shipped config.yaml)
+                                                                           (0, True, False, 0)])    # photometric + prior
+def test_process_problem_pipeline_bit_exact(pm, oracle, engine, geom_iterations, planar_prior, geom_pp, max_scale):
+    hostlib = importlib.import_module("mp-mvs_amd.hostlib")
+    sc = pm.synth.make_problem_scene(128, 96, n_src=4, spacing=0.4, quantize=True)
+    cams, imgs = sc.problem(0, [1, 2, 3, 4])
+    rng = np.random.default_rng(3)
+    src_depths = [sc.views[i].gt_depth * (1.0 + 0.005 * rng.standard_normal((96, 128))).astype(np.float32) for i in (1, 2, 3, 4)]
+    depth, normal, cost = hostlib.run_pipeline(0, cams, imgs, max_scale, geom_iterations, planar_prior, geom_pp, 4242, src_depths)
+    planes, costs = oracle_pipeline(pm, oracle, hostlib, cams, imgs, src_depths, max_scale, geom_iterations, planar_prior, geom_pp, 4242)
+    assert np.array_equal(depth, planes[..., 3]) and np.array_equal(normal, planes[..., :3]) and np.array_equal(cost, costs)
+    gt = sc.views[0].gt_depth
+    assert (np.abs(depth - gt) / gt < 0.05).mean() > 0.85
+
+
+def test_scheduler_device_exchange_bit_exact(pm, oracle, engine):
+    """6 Problems on one GPU with depth maps exchanged in HBM (export -> gather
+    buffer -> set_src_depths_device) == the same schedule on the oracle with host arrays"""
+    sched = importlib.import_module("mp-mvs_amd.schedule")
+    sc, neigh = pm.synth.make_grid_scene(64, 48, 3, 2, spacing=0.5, rot_deg=1.0, quantize=True)
+    cams = [v.cam for v in sc.views]
+    imgs = [v.image for v in sc.views]
+    kw = dict(geom_iterations=2, planar_prior=True, geom_planar_prior=True, seed=99)
+    gpu = sched.SceneScheduler(cams, imgs, neigh, lambda: engine.create(0), device_tensors=True, max_scale=1)
+    cpu = sched.SceneScheduler(cams, imgs, neigh, oracle.create, device_tensors=False, max_scale=1)
+    rg, rc = gpu.run(**kw), cpu.run(**kw)
+    assert np.array_equal(gpu.all_depths.cpu().numpy(), cpu.all_depths)
+    for i in range(6):
+        assert np.array_equal(rg[i][0], rc[i][0]) and np.array_equal(rg[i][1], rc[i][1]), f"problem {i}"
