@@ -66,6 +66,31 @@ def load_scene(pm, w, h, v, quantize):
     return cams, imgs, sc.views[0].gt_depth
 
 
+def measured_traffic_bytes():
+    """HBM bytes per k_update launch (FETCH_SIZE + WRITE_SIZE, KiB at the L2's memory
+    side) from the committed rocprofv3 PMC passes of this same command
+    (profiles/, collected with tools/profile_gpu.sh: PMC cannot be read in-process)"""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    if not os.path.isdir(pdir):
+        return None
+    for name in sorted(os.listdir(pdir)):
+        if not name.endswith(".txt") or "pmc_summary" not in name:
+            continue
+        vals, sect, kern = {}, None, None
+        for line in open(os.path.join(pdir, name)):
+            t = line.strip()
+            if t.startswith("== pmc_"):
+                sect = t
+            elif t.startswith("k_"):
+                kern = t.split()[0]
+            elif kern == "k_update" and (t.startswith("FETCH_SIZE") or t.startswith("WRITE_SIZE")):
+                vals[t.split()[0]] = float(t.split("avg=")[1])
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            best = (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0   # last file in name order = latest round
+    return best
+
+
 def cpu_baseline(pm, seed, quantize):
     """the oracle (our CPU port; the reference has no CPU path) on a
     bounded sample of the same workload: same schedule, 480x360 instead of 1600x1200"""
@@ -183,7 +208,7 @@ def main():
                 "peak": PEAK_VALU_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(tflops / PEAK_VALU_TFLOPS, 4),
-                "traffic": None,
+                "traffic": measured_traffic_bytes(),
                 "avg_launch_ms": round(upd_avg_ms, 4),
                 "launches_timed": upd_n,
                 "algorithmic_flop_per_launch": flops_per_launch,

@@ -31,6 +31,13 @@ def load():
     """dlopen the HIP library and bind every entry point; raises if it is not built."""
     if "lib" in _cache:
         return _cache["lib"], _cache["fns"]
+    # torch bundles its own libamdhip64; if our library pulled in /opt/rocm's copy
+    # first, torch.cuda could no longer initialise in this process.  Importing
+    # torch first makes both share one HIP runtime (same soname).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = os.environ.get("MPMVS_HIP_LIB", LIB_PATH)  # override: A/B-ing kernel builds
     if not os.path.exists(path):
         raise RuntimeError(f"HIP library not built: {path} (run __graft_entry__.build() or make -C mp-mvs_amd/csrc)")
