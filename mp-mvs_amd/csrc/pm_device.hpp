@@ -262,17 +262,17 @@ PM_DEV float4 perturbed_normal(const ProblemDev& P, int px, int py, const float4
 // launch and parked in LDS:
 //   * the block's reference-image tile + halo is staged once into LDS
 //     (coalesced rows, read back as the 36 window taps of every pixel),
-//   * the 36 bilateral weights of a pixel live in a per-thread LDS column
-//     ([tap][thread], conflict free), leaving the VGPRs to the gather pipeline
-//     of the NCC loop.
-// LDS layout (one array, floats): [36 * kBlockThreads weights][tile].
+//   * the 36 bilateral weights w and products w*r of a pixel live in a
+//     per-thread LDS column of float2 ([tap][thread], one conflict-free
+//     ds_read_b64 per tap), leaving the VGPRs to the gather pipeline of the
+//     NCC loop.  (The kernels are register-limited to 2 blocks per CU, so the
+//     72 KB per block cost no occupancy.)
+// LDS layout (one array): [36 * kBlockThreads float2][tile floats].
 // ---------------------------------------------------------------------------
 constexpr int kBlockThreads = 256;
 
 struct RefWin {
-    const float* lw;   // this thread's weight column: lw[tap * kBlockThreads]
-    const float* lt;   // this thread's pixel inside the LDS tile
-    int tpitch;        // tile pitch in floats
+    const float2* lw;  // this thread's column of (w, w*r) pairs: lw[tap * kBlockThreads]
     float inv_w, mean_r, var_r;
 };
 
@@ -292,7 +292,7 @@ PM_DEV void load_ref_tile(const ProblemDev& P, float* tile, int x0, int y0, int 
 }
 
 // weights of pixel (px,py) -> LDS column `lw`; (lx,ly) = position inside the block
-PM_DEV void ref_window(float* lw, const float* tile, int tpitch, int lx, int ly, int step, int radius, float two_ss, float two_sc, RefWin& rw) {
+PM_DEV void ref_window(float2* lw, const float* tile, int tpitch, int lx, int ly, int step, int radius, float two_ss, float two_sc, RefWin& rw) {
     const float* ctr = tile + (ly + radius) * tpitch + (lx + radius);
     const float rc = ctr[0];
     float sw = 0.0f, swr = 0.0f, swrr = 0.0f;
@@ -307,7 +307,7 @@ PM_DEV void ref_window(float* lw, const float* tile, int tpitch, int lx, int ly,
             const float e = (-sd) / two_ss - __builtin_fabsf(r - rc) / two_sc;
             const float w = d_exp(e);
             const float wr = w * r;
-            lw[(a * 6 + b) * kBlockThreads] = w;
+            lw[(a * 6 + b) * kBlockThreads] = make_float2(w, wr);
             pw += w;
             pwr += wr;
             pwrr = __builtin_fmaf(wr, r, pwrr);
@@ -317,8 +317,6 @@ PM_DEV void ref_window(float* lw, const float* tile, int tpitch, int lx, int ly,
         swrr += pwrr;
     }
     rw.lw = lw;
-    rw.lt = ctr;
-    rw.tpitch = tpitch;
     rw.inv_w = 1.0f / sw;
     rw.mean_r = swr * rw.inv_w;
     const float mrr = swrr * rw.inv_w;
@@ -529,13 +527,11 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int s
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
             const float s = tap[b].value();
-            const float w = rw.lw[(a * 6 + b) * kBlockThreads];
-            const float r = rw.lt[(b * step - radius) * rw.tpitch + dx];
-            const float wr = w * r;
-            const float ws = w * s;
-            P1 = __builtin_fmaf(w, s, P1);
+            const float2 wv = rw.lw[(a * 6 + b) * kBlockThreads];
+            const float ws = wv.x * s;
+            P1 = __builtin_fmaf(wv.x, s, P1);
             P2 = __builtin_fmaf(ws, s, P2);
-            P3 = __builtin_fmaf(wr, s, P3);
+            P3 = __builtin_fmaf(wv.y, s, P3);
         }
         T1 += P1;
         T2 += P2;

@@ -354,3 +354,51 @@ def test_errors_are_reported_not_fatal(pm, engine):
     prm.num_images = 5
     with pytest.raises(RuntimeError, match="num_images"):
         gpu.run(prm, 1)
+
+
+# ---------------------------------------------------------------------------
+# BASELINE sizes
+# ---------------------------------------------------------------------------
+def test_cfg1_mid_size_bit_exact(pm, oracle, engine):
+    """cfg 1 shape at 400x300 (8 source views, single scale, 3 iterations): full parity
+    at a size the oracle still finishes in seconds"""
+    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, 400, 300, 8, spacing=0.3, quantize=True)
+    gpu.run(prm, SEED)
+    cpu.run(prm, SEED)
+    compare_state(gpu, cpu, "cfg1 400x300")
+    gt = sc.views[0].gt_depth
+    assert (np.abs(gpu.get()[0][..., 3] - gt) / gt < 0.01).mean() > 0.9
+
+
+def test_cfg1_full_size_properties(pm, engine):
+    """cfg 1 at its real size (1600x1200, 8 source views) through size-independent
+    properties: determinism for a seed, sensitivity to the seed, value ranges,
+    unit normals facing the camera, convergence to the analytic ground truth, and
+    both texture formats giving the same bits"""
+    sc = pm.synth.make_problem_scene(1600, 1200, n_src=8, quantize=True)
+    cams, imgs = sc.problem(0, list(range(1, 9)))
+    dmin, dmax = pm.synth.kernel_depth_range(cams[0])
+    prm = pm.PatchMatchParams(num_images=9, depth_min=float(dmin), depth_max=float(dmax), max_scale=0)
+    a, b = engine.create(0), engine.create(0)
+    b.set_texture_format(True)
+    for h in (a, b):
+        h.set_views(cams, imgs)
+        h.run(prm, SEED)
+    pa, ca = a.get()
+    pb, cb = b.get()
+    assert a.texture_format() == "u8" and b.texture_format() == "f32"
+    assert np.array_equal(pa, pb) and np.array_equal(ca, cb)
+    a.run(prm, SEED)
+    assert np.array_equal(a.get()[0], pa), "same seed, same bits"
+    a.run(prm, SEED + 1)
+    assert not np.array_equal(a.get()[0], pa)
+    assert np.isfinite(pa).all() and np.all((ca >= 0) & (ca <= 2))
+    assert pa[..., 3].min() >= dmin * 0.999 and pa[..., 3].max() <= dmax * 1.001
+    assert np.allclose(np.linalg.norm(pa[..., :3].astype(np.float64), axis=-1), 1.0, atol=1e-4)
+    v0 = sc.views[0]
+    ncam = pa[..., :3].astype(np.float64) @ v0.R.T          # world -> camera
+    u, v = np.meshgrid(np.arange(1600), np.arange(1200))
+    view = np.stack([(u - v0.K[0, 2]) / v0.K[0, 0], (v - v0.K[1, 2]) / v0.K[1, 1], np.ones_like(u, float)], -1)
+    assert ((ncam * view).sum(-1) <= 1e-6).mean() > 0.999
+    gt = v0.gt_depth
+    assert (np.abs(pa[..., 3] - gt) / gt < 0.01).mean() > 0.97
