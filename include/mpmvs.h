@@ -145,7 +145,7 @@ int mpmvs_eval_geom(mpmvs_ctx* ctx, const mpmvs_params* params, const void* plan
 /* ComputeHomography (src/PatchMatch.cu:228-279) for one plane and source view
  * (0-based); H9 receives 9 floats, row-major */
 int mpmvs_homography(mpmvs_ctx* ctx, const void* plane4, int src_view, void* H9);
-/* canonical device math, fn: 0 rcp, 1 exp, 2 sin, 3 cos, 4 acos */
+/* canonical device math, fn: 0 rcp, 1 exp, 2 sin, 3 cos, 4 acos, 5 fract */
 int mpmvs_math(int fn, const void* in, void* out, int n);
 /* first n uniforms of RNG stream (seed, pixel, launch_id) */
 int mpmvs_rng(uint64_t seed, uint32_t pix, uint32_t launch_id, int n, void* out);

@@ -643,7 +643,7 @@ int mpmvs_homography(mpmvs_ctx* c, const void* plane4, int v, void* H9) {
 }
 
 int mpmvs_math(int fn, const void* in, void* out, int n) {
-    if (fn < 0 || fn > 4 || n <= 0) return -1;
+    if (fn < 0 || fn > 5 || n <= 0) return -1;
     float *d_in = nullptr, *d_out = nullptr;
     if (hipMalloc(&d_in, (size_t)n * 4) != hipSuccess) return -100;
     if (hipMalloc(&d_out, (size_t)n * 4) != hipSuccess) return -100;

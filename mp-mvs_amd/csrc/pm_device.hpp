@@ -263,16 +263,18 @@ PM_DEV float4 perturbed_normal(const ProblemDev& P, int px, int py, const float4
 //   * the block's reference-image tile + halo is staged once into LDS
 //     (coalesced rows, read back as the 36 window taps of every pixel),
 //   * the 36 bilateral weights w and products w*r of a pixel live in a
-//     per-thread LDS column of float2 ([tap][thread], one conflict-free
-//     ds_read_b64 per tap), leaving the VGPRs to the gather pipeline of the
-//     NCC loop.  (The kernels are register-limited to 2 blocks per CU, so the
-//     72 KB per block cost no occupancy.)
-// LDS layout (one array): [36 * kBlockThreads float2][tile floats].
+//     per-thread LDS column of 18 float4 ([tap pair][thread], one conflict-free
+//     ds_read_b128 per tap pair), leaving the VGPRs to the gather pipeline of
+//     the NCC loop.  (The kernels are register-limited to 2 blocks per CU, so
+//     the 72 KB per block cost no occupancy.)
+// LDS layout (one array): [18 * kBlockThreads float4][tile floats].
 // ---------------------------------------------------------------------------
 constexpr int kBlockThreads = 256;
 
 struct RefWin {
-    const float2* lw;  // this thread's column of (w, w*r) pairs: lw[tap * kBlockThreads]
+    // this thread's LDS column, one float4 per pair of vertically adjacent taps
+    // (b = 2j, 2j+1 of window column a): (w_even, w_odd, w*r_even, w*r_odd)
+    const float4* lw;  // lw[(a * 3 + j) * kBlockThreads]
     float inv_w, mean_r, var_r;
 };
 
@@ -292,13 +294,14 @@ PM_DEV void load_ref_tile(const ProblemDev& P, float* tile, int x0, int y0, int 
 }
 
 // weights of pixel (px,py) -> LDS column `lw`; (lx,ly) = position inside the block
-PM_DEV void ref_window(float2* lw, const float* tile, int tpitch, int lx, int ly, int step, int radius, float two_ss, float two_sc, RefWin& rw) {
+PM_DEV void ref_window(float4* lw, const float* tile, int tpitch, int lx, int ly, int step, int radius, float two_ss, float two_sc, RefWin& rw) {
     const float* ctr = tile + (ly + radius) * tpitch + (lx + radius);
     const float rc = ctr[0];
     float sw = 0.0f, swr = 0.0f, swrr = 0.0f;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
         float pw = 0.0f, pwr = 0.0f, pwrr = 0.0f;
+        float wv[6], wrv[6];
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
             const int dx = a * step - radius, dy = b * step - radius;
@@ -307,11 +310,14 @@ PM_DEV void ref_window(float2* lw, const float* tile, int tpitch, int lx, int ly
             const float e = (-sd) / two_ss - __builtin_fabsf(r - rc) / two_sc;
             const float w = d_exp(e);
             const float wr = w * r;
-            lw[(a * 6 + b) * kBlockThreads] = make_float2(w, wr);
+            wv[b] = w;
+            wrv[b] = wr;
             pw += w;
             pwr += wr;
             pwrr = __builtin_fmaf(wr, r, pwrr);
         }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) lw[(a * 3 + j) * kBlockThreads] = make_float4(wv[2 * j], wv[2 * j + 1], wrv[2 * j], wrv[2 * j + 1]);
         sw += pw;
         swr += pwr;
         swrr += pwrr;
@@ -360,26 +366,13 @@ PM_DEV SrcTex make_src_tex(const ViewDev& vw) {
     return t;
 }
 
-// software bilinear fetch with clamp addressing (CUDA tex2D(t, x+0.5, y+0.5),
-// linear filter; ref .cu:377, SURVEY a-2).  The image carries a one-texel
-// replicated apron, so clamping the coordinate to [-1, w-1] x [-1, h-1] makes
-// all four taps in-bounds and two 8-byte loads fetch them.  max/min give the
-// canonical NaN -> -1 behaviour of DESIGN.md 3.4 (maxNum returns the number).
-// (A row-pair interleaved layout with ONE 16-byte load per tap was measured
-// slower: 8.9 vs 8.1 ms per update launch, the doubled cache footprint costs
-// more than the halved instruction count saves.)
-PM_DEV float bilinear(const SrcTex& t, float sx, float sy) {
-    const float cx = clamp_coord(sx, t.wm1);
-    const float cy = clamp_coord(sy, t.hm1);
-    const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy);
-    const float ax = cx - fx, ay = cy - fy;
-    const int off = texel_offset((int)fy + 1, (int)fx + 1, t.pitch);
-    const f32x2 r0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(t.rsrc, off, 0, 0));
-    const f32x2 r1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(t.rsrc, off, t.row_bytes, 0));
-    const float top = __builtin_fmaf(ax, r0.y - r0.x, r0.x);
-    const float bot = __builtin_fmaf(ax, r1.y - r1.x, r1.x);
-    return __builtin_fmaf(ay, bot - top, top);
-}
+// Software bilinear fetch with clamp addressing (CUDA tex2D(t, x+0.5, y+0.5), linear
+// filter; ref .cu:377, SURVEY a-2): see BilinearTap below.  The padded image
+// carries a one-texel replicated apron, so clamping the coordinate to
+// [-1, w-1] x [-1, h-1] makes all four texels in-bounds; two 8-byte loads fetch
+// them.  (A row-pair interleaved fp32 layout with ONE 16-byte load per tap was
+// measured slower: its doubled cache footprint costs more than the halved
+// instruction count saves.)
 
 // Quad-packed 8-bit texture, used when every pixel of every source image is an
 // integer in [0, 255] (always true for the reference's input unless it rescales:
@@ -405,22 +398,9 @@ PM_DEV SrcTex8 make_src_tex8(const ViewDev& vw) {
     return t;
 }
 
-PM_DEV float bilinear(const SrcTex8& t, float sx, float sy) {
-    const float cx = clamp_coord(sx, t.wm1);
-    const float cy = clamp_coord(sy, t.hm1);
-    const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy);
-    const float ax = cx - fx, ay = cy - fy;
-    const int off = texel_offset((int)fy + 1, (int)fx + 1, t.pitch);
-    const uint32_t q = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(t.rsrc, off, 0, 0);
-    const float t00 = (float)(q & 0xffu), t10 = (float)((q >> 8) & 0xffu);
-    const float t01 = (float)((q >> 16) & 0xffu), t11 = (float)(q >> 24);
-    const float top = __builtin_fmaf(ax, t10 - t00, t00);
-    const float bot = __builtin_fmaf(ax, t11 - t01, t01);
-    return __builtin_fmaf(ay, bot - top, top);
-}
-
-// split form of bilinear(): issue() computes the address and starts the loads,
-// value() interpolates; lets a whole window column be in flight at once
+// Bilinear tap in two halves: issue() clamps the coordinate, computes the address
+// and starts the load(s); value() interpolates.  Lets a whole window column be
+// in flight at once.
 template <bool U8>
 struct BilinearTap;
 
@@ -431,10 +411,9 @@ struct BilinearTap<false> {
     PM_DEV void issue(const SrcTex& t, float sx, float sy) {
         const float cx = clamp_coord(sx, t.wm1);
         const float cy = clamp_coord(sy, t.hm1);
-        const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy);
-        ax = cx - fx;
-        ay = cy - fy;
-        const int off = texel_offset((int)fy + 1, (int)fx + 1, t.pitch);
+        ax = __builtin_amdgcn_fractf(cx);  // v_fract_f32: x - floor(x), kept below 1
+        ay = __builtin_amdgcn_fractf(cy);
+        const int off = texel_offset((int)__builtin_floorf(cy) + 1, (int)__builtin_floorf(cx) + 1, t.pitch);
         r0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(t.rsrc, off, 0, 0));
         r1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(t.rsrc, off, t.row_bytes, 0));
     }
@@ -452,10 +431,9 @@ struct BilinearTap<true> {
     PM_DEV void issue(const SrcTex8& t, float sx, float sy) {
         const float cx = clamp_coord(sx, t.wm1);
         const float cy = clamp_coord(sy, t.hm1);
-        const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy);
-        ax = cx - fx;
-        ay = cy - fy;
-        const int off = texel_offset((int)fy + 1, (int)fx + 1, t.pitch);
+        ax = __builtin_amdgcn_fractf(cx);  // v_fract_f32: x - floor(x), kept below 1
+        ay = __builtin_amdgcn_fractf(cy);
+        const int off = texel_offset((int)__builtin_floorf(cy) + 1, (int)__builtin_floorf(cx) + 1, t.pitch);
         q = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(t.rsrc, off, 0, 0);
     }
     PM_DEV float value() const {
@@ -503,39 +481,65 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int s
         if (!(cx >= 0.0f && cx < vw.wf && cy >= 0.0f && cy < vw.hf)) return 2.0f;  // ref .cu:351-353
     }
     float T1 = 0.0f, T2 = 0.0f, T3 = 0.0f;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-        const int dx = a * step - radius;
-        const float tx = (float)(px + dx);
+    const f32x2 h1 = {H1, H1}, h4 = {H4, H4}, h7 = {H7, H7};
+
+    // phase 1 of window column a: warp its 6 taps as 3 packed pairs, share ONE
+    // reciprocal between the six perspective divides, compute the
+    // addresses and issue all gathers of the column back to back
+    auto issue_column = [&](int a, BilinearTap<U8>(&tap)[6]) {
+        const float tx = (float)(px + a * step - radius);
         const float Cx = __builtin_fmaf(H0, tx, H2);
         const float Cy = __builtin_fmaf(H3, tx, H5);
         const float Cz = __builtin_fmaf(H6, tx, H8);
-        // phase 1: warp the 6 taps of this window column and issue all their
-        // gathers back to back, so one memory round trip covers the column
-        BilinearTap<U8> tap[6];
+        const f32x2 cx2 = {Cx, Cx}, cy2 = {Cy, Cy}, cz2 = {Cz, Cz};
+        f32x2 XP[3], YP[3], ZP[3];
 #pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            const float ty = (float)(py + b * step - radius);
-            const float X = __builtin_fmaf(H1, ty, Cx);
-            const float Y = __builtin_fmaf(H4, ty, Cy);
-            const float Z = __builtin_fmaf(H7, ty, Cz);
-            const float rz = d_rcp(Z);
-            tap[b].issue(tex, X * rz, Y * rz);
+        for (int j = 0; j < 3; ++j) {
+            const f32x2 ty = {(float)(py + (2 * j) * step - radius), (float)(py + (2 * j + 1) * step - radius)};
+            XP[j] = __builtin_elementwise_fma(h1, ty, cx2);
+            YP[j] = __builtin_elementwise_fma(h4, ty, cy2);
+            ZP[j] = __builtin_elementwise_fma(h7, ty, cz2);
         }
-        // phase 2: interpolate and accumulate in the canonical order
-        float P1 = 0.0f, P2 = 0.0f, P3 = 0.0f;
+        const float q0 = ZP[0].x * ZP[0].y, q1 = ZP[1].x * ZP[1].y, q2 = ZP[2].x * ZP[2].y;
+        const float t = q0 * q1, u = q1 * q2, v = q0 * q2;
+        const float r = d_rcp(t * q2);
+        const float iq[3] = {r * u, r * v, r * t};
 #pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            const float s = tap[b].value();
-            const float2 wv = rw.lw[(a * 6 + b) * kBlockThreads];
-            const float ws = wv.x * s;
-            P1 = __builtin_fmaf(wv.x, s, P1);
-            P2 = __builtin_fmaf(ws, s, P2);
-            P3 = __builtin_fmaf(wv.y, s, P3);
+        for (int j = 0; j < 3; ++j) {
+            const f32x2 zs = {ZP[j].y, ZP[j].x};
+            const f32x2 inv = (f32x2){iq[j], iq[j]} * zs;
+            const f32x2 sx = XP[j] * inv, sy = YP[j] * inv;
+            tap[2 * j].issue(tex, sx.x, sy.x);
+            tap[2 * j + 1].issue(tex, sx.y, sy.y);
         }
-        T1 += P1;
-        T2 += P2;
-        T3 += P3;
+    };
+    // phase 2: interpolate; even/odd taps accumulate in the two halves of packed registers
+    auto consume_column = [&](int a, const BilinearTap<U8>(&tap)[6]) {
+        f32x2 A1 = {0.0f, 0.0f}, A2 = {0.0f, 0.0f}, A3 = {0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const f32x2 sv = {tap[2 * j].value(), tap[2 * j + 1].value()};
+            const float4 wq = rw.lw[(a * 3 + j) * kBlockThreads];
+            const f32x2 w2 = {wq.x, wq.y}, wr2 = {wq.z, wq.w};
+            const f32x2 ws = w2 * sv;
+            A1 = __builtin_elementwise_fma(w2, sv, A1);
+            A2 = __builtin_elementwise_fma(ws, sv, A2);
+            A3 = __builtin_elementwise_fma(wr2, sv, A3);
+        }
+        T1 += A1.x + A1.y;
+        T2 += A2.x + A2.y;
+        T3 += A3.x + A3.y;
+    };
+    // software pipeline over the 6 columns: the gathers of column a+1 are in
+    // flight while column a is interpolated, so a wave never drains its loads
+    BilinearTap<U8> tapA[6], tapB[6];
+    issue_column(0, tapA);
+#pragma unroll
+    for (int a = 0; a < 6; a += 2) {
+        issue_column(a + 1, tapB);
+        consume_column(a, tapA);
+        if (a + 2 < 6) issue_column(a + 2, tapA);
+        consume_column(a + 1, tapB);
     }
     const float ms = T1 * rw.inv_w, mss = T2 * rw.inv_w, mrs = T3 * rw.inv_w;
     const float var_s = __builtin_fmaf(-ms, ms, mss);

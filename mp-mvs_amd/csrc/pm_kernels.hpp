@@ -95,7 +95,7 @@ PM_DEV bool dense_pixel(const ProblemDev& P, int& x, int& y) {
     return dense_pixel(P, x, y, x0, y0);
 }
 
-// dynamic LDS of the NCC kernels: 36 (w, w*r) pairs per thread + the reference tile
+// dynamic LDS of the NCC kernels: 18 float4 weight records per thread + the reference tile
 extern __shared__ float pm_lds[];
 constexpr int kLdsWeightFloats = 2 * 36 * kBlockThreads;
 inline size_t ncc_lds_bytes(int bw, int bh, int scale) {
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_init(const ProblemDe
     const int V = P.V;
     Rng g = rng_make(a.seed, (uint32_t)idx, a.launch);
     RefWin rw;
-    ref_window((float2*)pm_lds + threadIdx.x, tile, tpitch, x - x0, y - y0, step, radius, a.two_ss, a.two_sc, rw);
+    ref_window((float4*)pm_lds + threadIdx.x, tile, tpitch, x - x0, y - y0, step, radius, a.two_ss, a.two_sc, rw);
 
     float4 pl;
     if (a.init_random) {
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
     const int idx = y * W + x;
     Rng g = rng_make(a.seed, (uint32_t)idx, a.launch);
     RefWin rw;
-    ref_window((float2*)pm_lds + threadIdx.x, tile, tpitch, x - x0, y - y0, step, radius, a.two_ss, a.two_sc, rw);
+    ref_window((float4*)pm_lds + threadIdx.x, tile, tpitch, x - x0, y - y0, step, radius, a.two_ss, a.two_sc, rw);
 
     // -- 8 sampling regions: position of the lowest stored cost (ref .cu:798-816)
     int pos[8];
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_eval_ncc(const Probl
     if (!valid) return;
     const int idx = y * P.W + x;
     RefWin rw;
-    ref_window((float2*)pm_lds + threadIdx.x, tile, tpitch, x - x0, y - y0, step, radius, a.two_ss, a.two_sc, rw);
+    ref_window((float4*)pm_lds + threadIdx.x, tile, tpitch, x - x0, y - y0, step, radius, a.two_ss, a.two_sc, rw);
     float m0, m1, m2;
     plane_to_m(P, planes[idx], m0, m1, m2);
     const long wh = (long)P.W * P.H;
@@ -626,7 +626,8 @@ __global__ void k_math(int fn, const float* __restrict__ in, float* __restrict__
         case 1: y = d_exp(x); break;
         case 2: y = d_sin(x); break;
         case 3: y = d_cos(x); break;
-        default: y = d_acos(x); break;
+        case 4: y = d_acos(x); break;
+        default: y = __builtin_amdgcn_fractf(x); break;
     }
     out[i] = y;
 }

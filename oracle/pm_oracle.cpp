@@ -100,6 +100,13 @@ inline float det_rcp(float z) {
     return u2f(f2u(r) | (f2u(z) & 0x80000000u));
 }
 
+// fractional part as the GPU's V_FRACT_F32 computes it: x - floor(x), kept below 1
+// (a tiny negative x would otherwise round to 1.0)
+inline float det_fract(float x) {
+    const float f = x - floorf(x);
+    return (f < 0.99999994f) ? f : 0.99999994f;
+}
+
 // exp: Cody-Waite reduction by ln2 (hi/lo), degree-5 polynomial (Cephes expf
 // coefficients), exponent add through the integer representation.
 // x < -80 -> 0, x > 80 -> +inf, NaN -> NaN.
@@ -422,7 +429,7 @@ inline float bilinear(const Image& im, float sx, float sy) {
     float cy = (sy >= -1.0f) ? sy : -1.0f;
     cy = (cy <= hm1) ? cy : hm1;
     const float fx = floorf(cx), fy = floorf(cy);
-    const float ax = cx - fx, ay = cy - fy;
+    const float ax = det_fract(cx), ay = det_fract(cy);
     const int ix = (int)fx, iy = (int)fy;
     const float t00 = im.at(ix, iy), t10 = im.at(ix + 1, iy);
     const float t01 = im.at(ix, iy + 1), t11 = im.at(ix + 1, iy + 1);
@@ -461,23 +468,47 @@ inline float ncc_cost(const Ctx& c, const RefWin& rw, int px, int py, const floa
         const float Cx = fmaf(Hm[0], tx, Hm[2]);
         const float Cy = fmaf(Hm[3], tx, Hm[5]);
         const float Cz = fmaf(Hm[6], tx, Hm[8]);
-        float P1 = 0.0f, P2 = 0.0f, P3 = 0.0f;
+        float X[6], Y[6], Z[6], I[6];
         for (int b = 0; b < 6; ++b) {
             const float ty = (float)(py + rw.dx[b]);
-            const float X = fmaf(Hm[1], ty, Cx);
-            const float Y = fmaf(Hm[4], ty, Cy);
-            const float Z = fmaf(Hm[7], ty, Cz);
-            const float rz = det_rcp(Z);
-            const float s = bilinear(src, X * rz, Y * rz);
-            const float w = rw.w[a * 6 + b];
-            const float ws = w * s;
-            P1 = fmaf(w, s, P1);
-            P2 = fmaf(ws, s, P2);
-            P3 = fmaf(rw.wr[a * 6 + b], s, P3);
+            X[b] = fmaf(Hm[1], ty, Cx);
+            Y[b] = fmaf(Hm[4], ty, Cy);
+            Z[b] = fmaf(Hm[7], ty, Cz);
         }
-        T1 += P1;
-        T2 += P2;
-        T3 += P3;
+        // the six perspective divides of a window column share ONE reciprocal
+        // (DESIGN.md 3.3): 1/Z_i = rcp(prod Z) * prod_{j != i} Z_j, via pair products
+        {
+            const float q0 = Z[0] * Z[1], q1 = Z[2] * Z[3], q2 = Z[4] * Z[5];
+            const float t = q0 * q1, u = q1 * q2, v = q0 * q2;
+            const float r = det_rcp(t * q2);
+            const float iq0 = r * u, iq1 = r * v, iq2 = r * t;
+            I[0] = iq0 * Z[1];
+            I[1] = iq0 * Z[0];
+            I[2] = iq1 * Z[3];
+            I[3] = iq1 * Z[2];
+            I[4] = iq2 * Z[5];
+            I[5] = iq2 * Z[4];
+        }
+        // even and odd taps of the column accumulate separately (the GPU keeps
+        // them in the two halves of packed fp32 registers), then are added
+        float E1 = 0.0f, E2 = 0.0f, E3 = 0.0f, O1 = 0.0f, O2 = 0.0f, O3 = 0.0f;
+        for (int b = 0; b < 6; ++b) {
+            const float sv = bilinear(src, X[b] * I[b], Y[b] * I[b]);
+            const float w = rw.w[a * 6 + b];
+            const float ws = w * sv;
+            if ((b & 1) == 0) {
+                E1 = fmaf(w, sv, E1);
+                E2 = fmaf(ws, sv, E2);
+                E3 = fmaf(rw.wr[a * 6 + b], sv, E3);
+            } else {
+                O1 = fmaf(w, sv, O1);
+                O2 = fmaf(ws, sv, O2);
+                O3 = fmaf(rw.wr[a * 6 + b], sv, O3);
+            }
+        }
+        T1 += E1 + O1;
+        T2 += E2 + O2;
+        T3 += E3 + O3;
     }
     const float ms = T1 * rw.inv_w, mss = T2 * rw.inv_w, mrs = T3 * rw.inv_w;
     const float var_s = fmaf(-ms, ms, mss);
@@ -1174,7 +1205,7 @@ int orc_eval_geom(orc_ctx* h, const void* params, const float* planes_cam4, floa
     return 0;
 }
 
-// math probes: fn 0 rcp, 1 exp, 2 sin, 3 cos, 4 acos
+// math probes: fn 0 rcp, 1 exp, 2 sin, 3 cos, 4 acos, 5 fract
 int orc_math(int fn, const float* in, float* out, int n) {
     for (int i = 0; i < n; ++i) {
         const float x = in[i];
@@ -1185,6 +1216,7 @@ int orc_math(int fn, const float* in, float* out, int n) {
             case 2: y = det_sin(x); break;
             case 3: y = det_cos(x); break;
             case 4: y = det_acos(x); break;
+            case 5: y = det_fract(x); break;
             default: return -1;
         }
         out[i] = y;

@@ -135,7 +135,7 @@ def test_ncc_identical_views_cost_zero(pm, oracle):
     planes[..., 2] = -1.0
     planes[..., 3] = 5.0
     c = h.eval_ncc(prm, planes, 0)[0]
-    assert np.abs(c[8:40, 8:30]).max() < 1e-5
+    assert np.abs(c[8:40, 8:30]).max() < 1e-4 and np.abs(c[8:40, 8:30]).mean() < 1e-5
     assert np.all(c[10:38, 50:60] == 2.0)
 
 

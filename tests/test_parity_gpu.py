@@ -60,11 +60,14 @@ def random_planes(pm, cam, W, H, rng, dmin, dmax):
 # ---------------------------------------------------------------------------
 # canonical math + RNG
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("fn,lo,hi", [(0, -3000.0, 3000.0), (1, -90.0, 5.0), (2, -0.8, 0.8), (3, -0.8, 0.8), (4, -1.1, 1.1)])
+@pytest.mark.parametrize("fn,lo,hi", [(0, -3000.0, 3000.0), (1, -90.0, 5.0), (2, -0.8, 0.8), (3, -0.8, 0.8), (4, -1.1, 1.1), (5, -2.0, 1700.0)])
 def test_math_bit_exact(pm, oracle, engine, fn, lo, hi):
     rng = np.random.default_rng(fn)
     x = rng.uniform(lo, hi, 200000).astype(np.float32)
-    special = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 1e-30, -1e-30, 1e30, np.inf, -np.inf, np.nan, 80.0, -80.0, -80.5, 1.0000001], np.float32)
+    special = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 1e-30, -1e-30, 1e30, np.inf, -np.inf, np.nan, 80.0, -80.0, -80.5, 1.0000001,
+                        -1e-9, -2.0 ** -25, -2.0 ** -24, -2.0 ** -23, -0.99999994, 1599.9999, 7.0, -3e-8], np.float32)
+    if fn == 5:
+        special = special[np.isfinite(special)]  # the path only calls fract on clamped, finite coordinates
     x = np.concatenate([x, special])
     _, f_gpu = engine.load()
     got = pm._abi.math_probe(f_gpu, fn, x)
