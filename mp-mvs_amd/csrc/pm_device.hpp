@@ -329,11 +329,34 @@ PM_DEV void ref_window(float4* lw, const float* tile, int tpitch, int lx, int ly
     rw.var_r = __builtin_fmaf(-rw.mean_r, rw.mean_r, mrr);
 }
 
+// PM_PACKED=1 writes the tap-pair arithmetic on float2 vectors (v_pk_fma/mul_f32)
+#ifndef PM_PACKED
+#define PM_PACKED 1
+#endif
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // clamp a sample coordinate to [-1, hi]; NaN -> -1.  v_med3_f32
 // returns min3 when an input is NaN, which is exactly that rule.
 PM_DEV float clamp_coord(float s, float hi) { return __builtin_amdgcn_fmed3f(s, -1.0f, hi); }
+
+// floor + float->int in one instruction (hipcc only selects it under fast-math)
+PM_DEV int floor_to_int(float c) {
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(c));
+    return r;
+}
+// byte k of a packed dword as fp32 (kept as explicit instructions: left to itself
+// hipcc subtracts the bytes as integers first, through slower SDWA forms)
+template <int K>
+PM_DEV float ubyte_to_float(uint32_t q) {
+    float f;
+    if constexpr (K == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(q));
+    if constexpr (K == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(q));
+    if constexpr (K == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(q));
+    if constexpr (K == 3) asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(q));
+    return f;
+}
 
 // byte offset of padded texel (ix1, iy1), 4 bytes per texel; rows and pitch are
 // below 2^24, so the full-rate 24-bit multiply-add replaces v_mul_lo_u32
@@ -413,7 +436,7 @@ struct BilinearTap<false> {
         const float cy = clamp_coord(sy, t.hm1);
         ax = __builtin_amdgcn_fractf(cx);  // v_fract_f32: x - floor(x), kept below 1
         ay = __builtin_amdgcn_fractf(cy);
-        const int off = texel_offset((int)__builtin_floorf(cy) + 1, (int)__builtin_floorf(cx) + 1, t.pitch);
+        const int off = texel_offset(floor_to_int(cy) + 1, floor_to_int(cx) + 1, t.pitch);
         r0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(t.rsrc, off, 0, 0));
         r1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(t.rsrc, off, t.row_bytes, 0));
     }
@@ -433,12 +456,12 @@ struct BilinearTap<true> {
         const float cy = clamp_coord(sy, t.hm1);
         ax = __builtin_amdgcn_fractf(cx);  // v_fract_f32: x - floor(x), kept below 1
         ay = __builtin_amdgcn_fractf(cy);
-        const int off = texel_offset((int)__builtin_floorf(cy) + 1, (int)__builtin_floorf(cx) + 1, t.pitch);
+        const int off = texel_offset(floor_to_int(cy) + 1, floor_to_int(cx) + 1, t.pitch);
         q = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(t.rsrc, off, 0, 0);
     }
     PM_DEV float value() const {
-        const float t00 = (float)(q & 0xffu), t10 = (float)((q >> 8) & 0xffu);
-        const float t01 = (float)((q >> 16) & 0xffu), t11 = (float)(q >> 24);
+        const float t00 = ubyte_to_float<0>(q), t10 = ubyte_to_float<1>(q);
+        const float t01 = ubyte_to_float<2>(q), t11 = ubyte_to_float<3>(q);
         const float top = __builtin_fmaf(ax, t10 - t00, t00);
         const float bot = __builtin_fmaf(ax, t11 - t01, t01);
         return __builtin_fmaf(ay, bot - top, top);
@@ -486,6 +509,7 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int s
     // phase 1 of window column a: warp its 6 taps as 3 packed pairs, share ONE
     // reciprocal between the six perspective divides, compute the
     // addresses and issue all gathers of the column back to back
+#if PM_PACKED
     auto issue_column = [&](int a, BilinearTap<U8>(&tap)[6]) {
         const float tx = (float)(px + a * step - radius);
         const float Cx = __builtin_fmaf(H0, tx, H2);
@@ -530,6 +554,50 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int s
         T2 += A2.x + A2.y;
         T3 += A3.x + A3.y;
     };
+#else
+    auto issue_column = [&](int a, BilinearTap<U8>(&tap)[6]) {
+        const float tx = (float)(px + a * step - radius);
+        const float Cx = __builtin_fmaf(H0, tx, H2);
+        const float Cy = __builtin_fmaf(H3, tx, H5);
+        const float Cz = __builtin_fmaf(H6, tx, H8);
+        float X[6], Y[6], Z[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const float ty = (float)(py + b * step - radius);
+            X[b] = __builtin_fmaf(H1, ty, Cx);
+            Y[b] = __builtin_fmaf(H4, ty, Cy);
+            Z[b] = __builtin_fmaf(H7, ty, Cz);
+        }
+        const float q0 = Z[0] * Z[1], q1 = Z[2] * Z[3], q2 = Z[4] * Z[5];
+        const float t = q0 * q1, u = q1 * q2, v = q0 * q2;
+        const float r = d_rcp(t * q2);
+        const float iq[3] = {r * u, r * v, r * t};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float i0 = iq[j] * Z[2 * j + 1], i1 = iq[j] * Z[2 * j];
+            tap[2 * j].issue(tex, X[2 * j] * i0, Y[2 * j] * i0);
+            tap[2 * j + 1].issue(tex, X[2 * j + 1] * i1, Y[2 * j + 1] * i1);
+        }
+    };
+    auto consume_column = [&](int a, const BilinearTap<U8>(&tap)[6]) {
+        float E1 = 0.0f, E2 = 0.0f, E3 = 0.0f, O1 = 0.0f, O2 = 0.0f, O3 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float se = tap[2 * j].value(), so = tap[2 * j + 1].value();
+            const float4 wq = rw.lw[(a * 3 + j) * kBlockThreads];
+            const float wse = wq.x * se, wso = wq.y * so;
+            E1 = __builtin_fmaf(wq.x, se, E1);
+            O1 = __builtin_fmaf(wq.y, so, O1);
+            E2 = __builtin_fmaf(wse, se, E2);
+            O2 = __builtin_fmaf(wso, so, O2);
+            E3 = __builtin_fmaf(wq.z, se, E3);
+            O3 = __builtin_fmaf(wq.w, so, O3);
+        }
+        T1 += E1 + O1;
+        T2 += E2 + O2;
+        T3 += E3 + O3;
+    };
+#endif
     // software pipeline over the 6 columns: the gathers of column a+1 are in
     // flight while column a is interpolated, so a wave never drains its loads
     BilinearTap<U8> tapA[6], tapB[6];
