@@ -4,9 +4,9 @@
 //
 // HBM layout per context:
 //   reference image   (W+40) x (H+40) fp32, replicated apron 20  (window radius <= 20)
-//   source images     fp32 format: (w+2) x (h+2) fp32, replicated apron 1 (bilinear clamp for free)
-//                     u8 format (all images 8-bit exact): (w+1) x (h+1) dwords, each packing the
-//                     2x2 bilinear footprint of one texel (pm_device.hpp SrcTex8)
+//   source images     fp32 format: (w+1) x (h+1) fp32, last row/column replicated
+//                     u8 format (all images 8-bit exact): w x h dwords, each packing the 2x2
+//                     bilinear footprint of one texel (pm_device.hpp SrcTex8)
 //   source depth maps dense w x h fp32 (geometric consistency only)
 //   planes float4, costs f32, selected views u32, geometric costs f32 [H*W]
 //   prior planes float4 + mask u32 [H*W] (planar prior only)
@@ -170,14 +170,29 @@ static int upload_padded(mpmvs_ctx* c, const float* host, size_t pitch, int w, i
     return 0;
 }
 
+// host image -> dense staging buffer -> (w+1) x (h+1) fp32 texture (last row/column replicated)
+static int upload_extended(mpmvs_ctx* c, const float* host, size_t pitch, int w, int h, float** out) {
+    float* d_raw = nullptr;
+    HIPCHK(c, hipMalloc(&d_raw, (size_t)w * h * 4));
+    HIPCHK(c, hipMemcpy2DAsync(d_raw, (size_t)w * 4, host, pitch, (size_t)w * 4, h, hipMemcpyHostToDevice, c->stream));
+    float* d_e = nullptr;
+    HIPCHK(c, hipMalloc(&d_e, (size_t)(w + 1) * (h + 1) * 4));
+    hipLaunchKernelGGL(k_extend, dim3((w + 1 + 255) / 256, h + 1), dim3(256), 0, c->stream, d_raw, w, h, d_e);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(d_raw));
+    *out = d_e;
+    return 0;
+}
+
 // host image (integers 0..255) -> dense staging buffer -> quad-packed u8 texture
 static int upload_quads(mpmvs_ctx* c, const float* host, size_t pitch, int w, int h, uint32_t** out) {
     float* d_raw = nullptr;
     HIPCHK(c, hipMalloc(&d_raw, (size_t)w * h * 4));
     HIPCHK(c, hipMemcpy2DAsync(d_raw, (size_t)w * 4, host, pitch, (size_t)w * 4, h, hipMemcpyHostToDevice, c->stream));
     uint32_t* d_q = nullptr;
-    HIPCHK(c, hipMalloc(&d_q, (size_t)(w + 1) * (h + 1) * 4));
-    hipLaunchKernelGGL(k_pack_quads, dim3((w + 1 + 255) / 256, h + 1), dim3(256), 0, c->stream, d_raw, w, h, d_q);
+    HIPCHK(c, hipMalloc(&d_q, (size_t)w * h * 4));
+    hipLaunchKernelGGL(k_pack_quads, dim3((w + 255) / 256, h), dim3(256), 0, c->stream, d_raw, w, h, d_q);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipFree(d_raw));
@@ -279,12 +294,12 @@ int mpmvs_set_views(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* 
         ViewDev& o = c->hP.views[v - 1];
         if (exact) {
             if ((rc = upload_quads(c, images[v], pitch, w, h, &c->d_src8[v - 1]))) return rc;
-            o.pitch8 = w + 1;
+            o.pitch8 = w;
             o.img8 = c->d_src8[v - 1];
         } else {
-            if ((rc = upload_padded(c, images[v], pitch, w, h, kSrcApron, &c->d_src[v - 1]))) return rc;
-            o.pitch = w + 2 * kSrcApron;
-            o.img = c->d_src[v - 1] + (size_t)kSrcApron * o.pitch + kSrcApron;
+            if ((rc = upload_extended(c, images[v], pitch, w, h, &c->d_src[v - 1]))) return rc;
+            o.pitch = w + 1;
+            o.img = c->d_src[v - 1];
         }
     }
     const size_t wh = (size_t)c->W * c->H;

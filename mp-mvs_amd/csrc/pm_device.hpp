@@ -19,7 +19,6 @@ namespace pm {
 
 constexpr int kMaxViews = 32;   // ref .cu:500 and the u32 view mask
 constexpr int kRefApron = 20;   // widest NCC window radius (scale 2): ref .cu:342-346
-constexpr int kSrcApron = 1;    // replicated border that makes clamp addressing free
 
 // ---------------------------------------------------------------------------
 // device-resident problem description (uniform across a launch -> scalar loads)
@@ -36,10 +35,10 @@ struct ViewDev {
     float b[3];        // K_s t_rel
     float wf, hf;      // (float)width, (float)height
     float wm1, hm1;    // (float)(width-1), (float)(height-1)
-    const float* img;  // texel (0,0) of the apron-padded source image (fp32 format)
-    int pitch;         // floats per padded row
+    const float* img;  // fp32 format: (w+1) x (h+1) image, last row/column replicated
+    int pitch;         // floats per row (= w + 1)
     const uint32_t* img8;  // quad-packed u8 texture (see SrcTex8) or null
-    int pitch8;            // dwords per row of the quad-packed texture (= w + 1)
+    int pitch8;            // dwords per row of the quad-packed texture (= w)
     int w, h;
     const float* depth;  // dense source depth map (geometric consistency) or null
     int dw, dh;
@@ -336,9 +335,13 @@ PM_DEV void ref_window(float4* lw, const float* tile, int tpitch, int lx, int ly
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// clamp a sample coordinate to [-1, hi]; NaN -> -1.  v_med3_f32
-// returns min3 when an input is NaN, which is exactly that rule.
-PM_DEV float clamp_coord(float s, float hi) { return __builtin_amdgcn_fmed3f(s, -1.0f, hi); }
+// Clamp a sample coordinate to [0, hi] (hi = size - 1); NaN -> 0 (v_med3_f32 returns
+// min3 when an input is NaN).  The canonical rule is clamp addressing of the
+// TEXELS: below 0 both texels of the pair are texel 0 and above
+// hi both are texel hi, so the interpolated value does not depend on the fraction
+// there and clamping the coordinate itself gives the same bits -- with no apron
+// and non-negative texel indices.
+PM_DEV float clamp_coord(float s, float hi) { return __builtin_amdgcn_fmed3f(s, 0.0f, hi); }
 
 // floor + float->int in one instruction (hipcc only selects it under fast-math)
 PM_DEV int floor_to_int(float c) {
@@ -358,10 +361,10 @@ PM_DEV float ubyte_to_float(uint32_t q) {
     return f;
 }
 
-// byte offset of padded texel (ix1, iy1), 4 bytes per texel; rows and pitch are
-// below 2^24, so the full-rate 24-bit multiply-add replaces v_mul_lo_u32
-PM_DEV int texel_offset(int iy1, int ix1, int pitch) {
-    return (int)((__umul24((unsigned)iy1, (unsigned)pitch) + (unsigned)ix1) << 2);
+// byte offset of texel (ix, iy) >= 0, 4 bytes per texel; rows and pitch are
+// below 2^24, so the full-rate 24-bit multiply replaces v_mul_lo_u32
+PM_DEV int texel_offset(int iy, int ix, int pitch) {
+    return (int)((__umul24((unsigned)iy, (unsigned)pitch) + (unsigned)ix) << 2);
 }
 
 // Per-view source image handle: a 128-bit buffer resource (wave-uniform, built
@@ -382,18 +385,16 @@ PM_DEV SrcTex make_src_tex(const ViewDev& vw) {
     t.row_bytes = vw.pitch * 4;
     t.wm1 = vw.wm1;
     t.hm1 = vw.hm1;
-    // resource base = first byte of the padded allocation (texel (-1,-1))
-    const float* base = vw.img - (vw.pitch + 1);
-    const int bytes = vw.pitch * (vw.h + 2 * kSrcApron) * 4;
-    t.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, bytes, 0x00020000);
+    const int bytes = vw.pitch * (vw.h + 1) * 4;
+    t.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vw.img), (short)0, bytes, 0x00020000);
     return t;
 }
 
 // Software bilinear fetch with clamp addressing (CUDA tex2D(t, x+0.5, y+0.5), linear
-// filter; ref .cu:377, SURVEY a-2): see BilinearTap below.  The padded image
-// carries a one-texel replicated apron, so clamping the coordinate to
-// [-1, w-1] x [-1, h-1] makes all four texels in-bounds; two 8-byte loads fetch
-// them.  (A row-pair interleaved fp32 layout with ONE 16-byte load per tap was
+// filter; ref .cu:377, SURVEY a-2): see BilinearTap below.  The resident image has
+// one replicated extra row and column (w+1 x h+1), so with the coordinate clamped
+// to [0, w-1] x [0, h-1] the four texels of a tap are always in-bounds; two 8-byte
+// loads fetch them.  (A row-pair interleaved fp32 layout with ONE 16-byte load per tap was
 // measured slower: its doubled cache footprint costs more than the halved
 // instruction count saves.)
 
@@ -416,7 +417,7 @@ PM_DEV SrcTex8 make_src_tex8(const ViewDev& vw) {
     t.pitch = vw.pitch8;
     t.wm1 = vw.wm1;
     t.hm1 = vw.hm1;
-    const int bytes = vw.pitch8 * (vw.h + 1) * 4;
+    const int bytes = vw.pitch8 * vw.h * 4;
     t.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(vw.img8), (short)0, bytes, 0x00020000);
     return t;
 }
@@ -436,7 +437,7 @@ struct BilinearTap<false> {
         const float cy = clamp_coord(sy, t.hm1);
         ax = __builtin_amdgcn_fractf(cx);  // v_fract_f32: x - floor(x), kept below 1
         ay = __builtin_amdgcn_fractf(cy);
-        const int off = texel_offset(floor_to_int(cy) + 1, floor_to_int(cx) + 1, t.pitch);
+        const int off = texel_offset(floor_to_int(cy), floor_to_int(cx), t.pitch);
         r0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(t.rsrc, off, 0, 0));
         r1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(t.rsrc, off, t.row_bytes, 0));
     }
@@ -456,7 +457,7 @@ struct BilinearTap<true> {
         const float cy = clamp_coord(sy, t.hm1);
         ax = __builtin_amdgcn_fractf(cx);  // v_fract_f32: x - floor(x), kept below 1
         ay = __builtin_amdgcn_fractf(cy);
-        const int off = texel_offset(floor_to_int(cy) + 1, floor_to_int(cx) + 1, t.pitch);
+        const int off = texel_offset(floor_to_int(cy), floor_to_int(cx), t.pitch);
         q = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(t.rsrc, off, 0, 0);
     }
     PM_DEV float value() const {

@@ -559,17 +559,22 @@ __global__ void k_pad(const float* __restrict__ src, int w, int h, float* __rest
     dst[(long)y * pw + x] = src[(long)sy * w + sx];
 }
 
-// dense w x h image of integers in [0,255] -> quad-packed u8 texture (SrcTex8)
+// dense w x h image of integers in [0,255] -> quad-packed u8 texture (SrcTex8), w x h dwords
 __global__ void k_pack_quads(const float* __restrict__ src, int w, int h, uint32_t* __restrict__ dst) {
-    const int pw = w + 1;
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= pw || y >= h + 1) return;
-    // padded P[py][px] = src[clamp(py-1)][clamp(px-1)]
-    const int x0 = x - 1 < 0 ? 0 : x - 1, x1 = x > w - 1 ? w - 1 : x;
-    const int y0 = y - 1 < 0 ? 0 : y - 1, y1 = y > h - 1 ? h - 1 : y;
-    const uint32_t b0 = (uint32_t)src[(long)y0 * w + x0], b1 = (uint32_t)src[(long)y0 * w + x1];
-    const uint32_t b2 = (uint32_t)src[(long)y1 * w + x0], b3 = (uint32_t)src[(long)y1 * w + x1];
-    dst[(long)y * pw + x] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    if (x >= w || y >= h) return;
+    const int x1 = x + 1 > w - 1 ? w - 1 : x + 1, y1 = y + 1 > h - 1 ? h - 1 : y + 1;
+    const uint32_t b0 = (uint32_t)src[(long)y * w + x], b1 = (uint32_t)src[(long)y * w + x1];
+    const uint32_t b2 = (uint32_t)src[(long)y1 * w + x], b3 = (uint32_t)src[(long)y1 * w + x1];
+    dst[(long)y * w + x] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+}
+
+// dense w x h image -> (w+1) x (h+1) image with the last row and column replicated
+__global__ void k_extend(const float* __restrict__ src, int w, int h, float* __restrict__ dst) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x > w || y > h) return;
+    const int sx = x > w - 1 ? w - 1 : x, sy = y > h - 1 ? h - 1 : y;
+    dst[(long)y * (w + 1) + x] = src[(long)sy * w + sx];
 }
 
 __global__ void k_export_depth(const float4* __restrict__ planes, float* __restrict__ out, int n) {
