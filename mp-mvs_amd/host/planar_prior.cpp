@@ -94,17 +94,34 @@ struct Mesh {
     std::vector<Tri> tris;
     std::vector<char> dead;
     int last = 0;
+    // scratch reused across inserts (no allocation in the steady state)
+    struct Edge {
+        int a, b, outer, tri;
+    };
+    std::vector<int> cavity, stack;
+    std::vector<Edge> edges;
 
+    // vertices 0..2 are the far-away super triangle: only predicates touching them
+    // need 128 bits, image points (|coord| < 2^15) fit the 64-bit fast path exactly
     i128 orient(int a, int b, int c) const {
+        if (a >= 3 && b >= 3 && c >= 3)
+            return (i128)((px[b] - px[a]) * (py[c] - py[a]) - (py[b] - py[a]) * (px[c] - px[a]));
         return (i128)(px[b] - px[a]) * (py[c] - py[a]) - (i128)(py[b] - py[a]) * (px[c] - px[a]);
     }
     // > 0: d strictly inside the circumcircle of counter-clockwise (a, b, c)
-    i128 incircle(int a, int b, int c, int d) const {
+    bool incircle_pos(int a, int b, int c, int d) const {
+        if (a >= 3 && b >= 3 && c >= 3 && d >= 3) {
+            const long long ax = px[a] - px[d], ay = py[a] - py[d];
+            const long long bx = px[b] - px[d], by = py[b] - py[d];
+            const long long cx = px[c] - px[d], cy = py[c] - py[d];
+            const long long a2 = ax * ax + ay * ay, b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
+            return ax * (by * c2 - b2 * cy) - ay * (bx * c2 - b2 * cx) + a2 * (bx * cy - by * cx) > 0;
+        }
         const i128 ax = px[a] - px[d], ay = py[a] - py[d];
         const i128 bx = px[b] - px[d], by = py[b] - py[d];
         const i128 cx = px[c] - px[d], cy = py[c] - py[d];
         const i128 a2 = ax * ax + ay * ay, b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
-        return ax * (by * c2 - b2 * cy) - ay * (bx * c2 - b2 * cx) + a2 * (bx * cy - by * cx);
+        return ax * (by * c2 - b2 * cy) - ay * (bx * c2 - b2 * cx) + a2 * (bx * cy - by * cx) > 0;
     }
     int locate(int p) {
         int t = last;
@@ -127,8 +144,9 @@ struct Mesh {
         for (int i = 0; i < 3; ++i)
             if (px[tris[t0].v[i]] == px[p] && py[tris[t0].v[i]] == py[p]) return false;  // duplicate point
         // cavity = connected set of triangles whose circumcircle strictly contains p
-        std::vector<int> cavity, stack;
-        std::vector<int> mark_list;
+        cavity.clear();
+        stack.clear();
+        edges.clear();
         stack.push_back(t0);
         dead[t0] = 2;
         while (!stack.empty()) {
@@ -138,16 +156,12 @@ struct Mesh {
             for (int i = 0; i < 3; ++i) {
                 const int nb = tris[t].n[i];
                 if (nb < 0 || dead[nb]) continue;
-                if (incircle(tris[nb].v[0], tris[nb].v[1], tris[nb].v[2], p) > 0) {
+                if (incircle_pos(tris[nb].v[0], tris[nb].v[1], tris[nb].v[2], p)) {
                     dead[nb] = 2;
                     stack.push_back(nb);
                 }
             }
         }
-        struct Edge {
-            int a, b, outer, tri;
-        };
-        std::vector<Edge> edges;
         for (int t : cavity)
             for (int i = 0; i < 3; ++i) {
                 const int nb = tris[t].n[i];
@@ -199,6 +213,10 @@ std::vector<Triangle> Delaunay(const Rect boundRC, const std::vector<Point>& poi
     (void)boundRC;
     m.px = {-K, 3 * K, -K};
     m.py = {-K, -K, 3 * K};
+    m.px.reserve(points.size() + 3);
+    m.py.reserve(points.size() + 3);
+    m.tris.reserve(points.size() * 7 + 16);
+    m.dead.reserve(points.size() * 7 + 16);
     Tri t0;
     t0.v[0] = 0;
     t0.v[1] = 1;
@@ -206,11 +224,28 @@ std::vector<Triangle> Delaunay(const Rect boundRC, const std::vector<Point>& poi
     t0.n[0] = t0.n[1] = t0.n[2] = -1;
     m.tris.push_back(t0);
     m.dead.push_back(0);
+    // Insertion order: the vertices arrive sorted by 5x5 cell in row-major order,
+    // which makes every new point fall just outside the current hull and blows the
+    // Bowyer-Watson cavities up (measured: 23 triangles per insert).  A biased
+    // multi-level order -- cells on a stride-8 lattice first, then stride 4, 2, 1,
+    // row-major inside each level -- keeps cavities at ~5 triangles and walks
+    // short.  Deterministic; the triangulation itself does not depend on the order
+    // (up to cocircular ties).
+    std::vector<int> order(points.size());
+    for (size_t i = 0; i < points.size(); ++i) order[i] = (int)i;
+    auto level = [&](int i) {
+        const int cx = points[i].x / 5, cy = points[i].y / 5;
+        if (cx % 8 == 0 && cy % 8 == 0) return 0;
+        if (cx % 4 == 0 && cy % 4 == 0) return 1;
+        if (cx % 2 == 0 && cy % 2 == 0) return 2;
+        return 3;
+    };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return level(a) < level(b); });
     for (const Point& p : points) {
         m.px.push_back(p.x);
         m.py.push_back(p.y);
-        m.insert((int)m.px.size() - 1);
     }
+    for (int i : order) m.insert(i + 3);
     for (size_t t = 0; t < m.tris.size(); ++t) {
         if (m.dead[t]) continue;
         const Tri& T = m.tris[t];
@@ -264,14 +299,26 @@ static float depth_from_plane(const Camera& cam, const float4 pl, int x, int y) 
 void BuildPrior(const Camera& cam, int width, int height, const std::vector<Triangle>& triangles, const float4* planes,
                 float depth_min, float depth_max, std::vector<float4>& planeParams, Image& mask) {
     const Rect imageRC{0, 0, width, height};
-    mask = Image(height, width, 1, 0.0f);
-    planeParams.clear();
-    uint32_t idx = 0;
-    for (const Triangle& t : triangles) {
-        if (!(imageRC.contains(t.pt1) && imageRC.contains(t.pt2) && imageRC.contains(t.pt3))) continue;
-        const float L01 = (float)std::sqrt(std::pow(t.pt1.x - t.pt2.x, 2) + std::pow(t.pt1.y - t.pt2.y, 2));
-        const float L02 = (float)std::sqrt(std::pow(t.pt1.x - t.pt3.x, 2) + std::pow(t.pt1.y - t.pt3.y, 2));
-        const float L12 = (float)std::sqrt(std::pow(t.pt2.x - t.pt3.x, 2) + std::pow(t.pt2.y - t.pt3.y, 2));
+    // triangles the reference keeps (all three vertices inside the image), in order:
+    // triangle k gets label k + 1 and its plane is planeParams[k]
+    std::vector<int> keep;
+    keep.reserve(triangles.size());
+    for (size_t i = 0; i < triangles.size(); ++i) {
+        const Triangle& t = triangles[i];
+        if (imageRC.contains(t.pt1) && imageRC.contains(t.pt2) && imageRC.contains(t.pt3)) keep.push_back((int)i);
+    }
+    planeParams.assign(keep.size(), float4{0, 0, 0, 0});
+    // A pixel covered by several triangles keeps the label of the LAST one in the
+    // reference's sequential loop = the largest label: an atomic max over triangles
+    // processed in parallel gives the same mask.
+    std::vector<uint32_t> label((size_t)width * height, 0u);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (long k = 0; k < (long)keep.size(); ++k) {
+        const Triangle& t = triangles[keep[k]];
+        const uint32_t lab = (uint32_t)k + 1u;
+        const float L01 = (float)std::sqrt((double)((t.pt1.x - t.pt2.x) * (t.pt1.x - t.pt2.x) + (t.pt1.y - t.pt2.y) * (t.pt1.y - t.pt2.y)));
+        const float L02 = (float)std::sqrt((double)((t.pt1.x - t.pt3.x) * (t.pt1.x - t.pt3.x) + (t.pt1.y - t.pt3.y) * (t.pt1.y - t.pt3.y)));
+        const float L12 = (float)std::sqrt((double)((t.pt2.x - t.pt3.x) * (t.pt2.x - t.pt3.x) + (t.pt2.y - t.pt3.y) * (t.pt2.y - t.pt3.y)));
         const float max_edge = std::max(L01, std::max(L02, L12));
         const float step = (float)(1.0 / max_edge);
         // barycentric stepping of the reference (src/PatchMatch.cpp:564-570)
@@ -279,20 +326,27 @@ void BuildPrior(const Camera& cam, int width, int height, const std::vector<Tria
             for (float q = 0; q < 1.0 - p; q += step) {
                 const int x = (int)((double)(p * (float)t.pt1.x + q * (float)t.pt2.x) + (1.0 - p - q) * t.pt3.x);
                 const int y = (int)((double)(p * (float)t.pt1.y + q * (float)t.pt2.y) + (1.0 - p - q) * t.pt3.y);
-                if (x >= 0 && y >= 0 && x < width && y < height) mask.at(y, x) = (float)(idx + 1.0);
+                if (x >= 0 && y >= 0 && x < width && y < height) {
+                    uint32_t* cell = &label[(size_t)y * width + x];
+                    uint32_t cur = __atomic_load_n(cell, __ATOMIC_RELAXED);
+                    while (cur < lab && !__atomic_compare_exchange_n(cell, &cur, lab, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+                    }
+                }
             }
             if (!(step > 0.0f) || !std::isfinite(step)) break;  // degenerate triangle: one sample
         }
-        planeParams.push_back(PriorPlane(cam, t, planes, width));
-        ++idx;
+        planeParams[k] = PriorPlane(cam, t, planes, width);
     }
+    mask = Image(height, width, 1, 0.0f);
+#pragma omp parallel for schedule(static)
     for (int j = 0; j < height; ++j)
-        for (int i = 0; i < width; ++i)
-            if (mask.at(j, i) > 0) {
-                const float4 n4 = planeParams[(size_t)mask.at(j, i) - 1];
-                const float d = depth_from_plane(cam, n4, i, j);
-                if (!(d <= depth_max && d >= depth_min)) mask.at(j, i) = 0;
+        for (int i = 0; i < width; ++i) {
+            const uint32_t lab = label[(size_t)j * width + i];
+            if (lab > 0) {
+                const float d = depth_from_plane(cam, planeParams[lab - 1], i, j);
+                if (d <= depth_max && d >= depth_min) mask.at(j, i) = (float)lab;
             }
+        }
 }
 
 }  // namespace mpmvs_host
