@@ -405,3 +405,72 @@ def test_cfg1_full_size_properties(pm, engine):
     assert ((ncam * view).sum(-1) <= 1e-6).mean() > 0.999
     gt = v0.gt_depth
     assert (np.abs(pa[..., 3] - gt) / gt < 0.01).mean() > 0.97
+
+
+# ---------------------------------------------------------------------------
+# edge cases (rare branches must agree bit for bit too)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("W,H", [(20, 12), (9, 7), (33, 5)])
+def test_tiny_images_bit_exact(pm, oracle, engine, W, H):
+    """images smaller than the propagation reach (23 px) and the largest window (41 px):
+    most sampling regions are empty, windows are mostly clamped border texels"""
+    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, W, H, 2, spacing=0.6, quantize=True)
+    prm.max_scale = 2
+    gpu.run(prm, SEED)
+    cpu.run(prm, SEED)
+    compare_state(gpu, cpu, f"tiny {W}x{H}")
+
+
+def test_max_source_views_bit_exact(pm, oracle, engine):
+    """32 source views = the reference's array bound (cost_vector[32]) and the full view bitmask"""
+    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, 48, 40, 32, spacing=0.5)
+    gpu.run(prm, SEED)
+    cpu.run(prm, SEED)
+    compare_state(gpu, cpu, "32 views")
+    assert (gpu.get_selected_views() >> 31).any(), "bit 31 of the view mask is in use"
+
+
+def test_textureless_and_out_of_view_bit_exact(pm, oracle, engine):
+    """flat image regions (variance < 1e-5 -> cost 2, ref .cu:406-408), a depth range
+    that throws most hypotheses out of the source images (ref .cu:351-353), and
+    pixels where no view is valid (cost 2, selected views 0, ref .cu:531-533)"""
+    sc = pm.synth.make_problem_scene(96, 64, n_src=3, spacing=0.5, quantize=True)
+    cams, imgs = sc.problem(0, [1, 2, 3])
+    imgs = [im.copy() for im in imgs]
+    for im in imgs:
+        im[:, 60:] = 77.0
+    imgs[0][20:40, 10:30] = 200.0
+    gpu, cpu = engine.create(0), oracle.create()
+    prm = pm.PatchMatchParams(num_images=4, depth_min=0.3, depth_max=9.0, max_scale=1)
+    for h in (gpu, cpu):
+        h.set_views(cams, imgs)
+        h.step(prm, SEED, pm.KIND_INIT, 0, 1, 0)
+    compare_state(gpu, cpu, "textureless init")
+    costs = gpu.get()[1]
+    assert (costs == 2.0).mean() > 0.2 and (gpu.get_selected_views()[costs == 2.0] == 0).all()
+    for h in (gpu, cpu):
+        h.run(prm, SEED)
+    compare_state(gpu, cpu, "textureless run")
+
+
+def test_geom_and_prior_with_many_views_bit_exact(pm, oracle, engine):
+    """geometric + prior modes on the > 8 views instantiation (MAXV = 32 kernels)"""
+    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, 64, 48, 10, spacing=0.5, quantize=True)
+    rng = np.random.default_rng(21)
+    ids = [1 + (i % 8) for i in range(10)]
+    depths = [sc.views[i].gt_depth * (1.0 + 0.005 * rng.standard_normal((48, 64))).astype(np.float32) for i in ids]
+    for h in (gpu, cpu):
+        h.run(prm, SEED)
+    compare_state(gpu, cpu, "photometric")
+    planes, costs = cpu.get()
+    prior, mask = _fake_prior(pm, sc, planes, costs, rng)
+    for h in (gpu, cpu):
+        h.set_src_depths(depths)
+        prm.geom_consistency, prm.planar_prior, prm.max_iterations = True, False, 2
+        h.run(prm, SEED + 1)
+    compare_state(gpu, cpu, "geom", geom=True)
+    for h in (gpu, cpu):
+        h.set_prior(prior, mask)
+        prm.geom_consistency, prm.planar_prior, prm.max_iterations = False, True, 3
+        h.run(prm, SEED + 2)
+    compare_state(gpu, cpu, "prior")
