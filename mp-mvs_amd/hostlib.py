@@ -10,7 +10,9 @@ from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "host", "libmpmvs_host.so")
-SYMBOLS = ["mpmvs_host_triangulate_vertices", "mpmvs_host_delaunay", "mpmvs_host_build_prior", "mpmvs_host_run_pipeline"]
+SYMBOLS = ["mpmvs_host_triangulate_vertices", "mpmvs_host_delaunay", "mpmvs_host_build_prior", "mpmvs_host_run_pipeline",
+           "mpmvs_host_write_dmb", "mpmvs_host_read_dmb", "mpmvs_host_read_camera", "mpmvs_host_sample_list", "mpmvs_host_read_pgm",
+           "mpmvs_host_run_folder"]
 _cache = {}
 
 
@@ -29,6 +31,18 @@ def load():
         lib.mpmvs_host_run_pipeline.restype = C.c_int
         lib.mpmvs_host_run_pipeline.argtypes = [C.c_int, C.c_int, C.POINTER(_abi.Camera), C.POINTER(C.POINTER(C.c_float)), C.c_int, C.c_int,
                                                 C.c_int, C.c_int, C.c_uint64, C.POINTER(C.POINTER(C.c_float)), P, P, P]
+        lib.mpmvs_host_write_dmb.restype = C.c_int
+        lib.mpmvs_host_write_dmb.argtypes = [C.c_char_p, P, C.c_int, C.c_int, C.c_int]
+        lib.mpmvs_host_read_dmb.restype = C.c_int
+        lib.mpmvs_host_read_dmb.argtypes = [C.c_char_p, P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.mpmvs_host_read_camera.restype = C.c_int
+        lib.mpmvs_host_read_camera.argtypes = [C.c_char_p, C.POINTER(_abi.Camera)]
+        lib.mpmvs_host_sample_list.restype = C.c_int
+        lib.mpmvs_host_sample_list.argtypes = [C.c_char_p, C.c_int, C.c_int, P, C.c_int]
+        lib.mpmvs_host_read_pgm.restype = C.c_int
+        lib.mpmvs_host_read_pgm.argtypes = [C.c_char_p, P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.mpmvs_host_run_folder.restype = C.c_int
+        lib.mpmvs_host_run_folder.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]
         _cache["lib"] = lib
     return _cache["lib"]
 
@@ -89,3 +103,87 @@ def run_pipeline(device, cams, images, max_scale, geom_iterations, planar_prior,
     if rc != 0:
         raise RuntimeError(f"mpmvs_host_run_pipeline failed ({rc})")
     return depth, normal, cost
+
+
+# ---- file formats (reference src/utility.cpp:193-308, src/PatchMatch.cpp:67-143) ------------
+def write_dmb(path, arr):
+    a = np.ascontiguousarray(arr, np.float32)
+    h, w = a.shape[:2]
+    nb = 1 if a.ndim == 2 else a.shape[2]
+    if load().mpmvs_host_write_dmb(str(path).encode(), a.ctypes.data, h, w, nb) != 0:
+        raise RuntimeError(f"cannot write {path}")
+
+
+def read_dmb(path):
+    lib = load()
+    h, w, nb = C.c_int(), C.c_int(), C.c_int()
+    if lib.mpmvs_host_read_dmb(str(path).encode(), None, 0, C.byref(h), C.byref(w), C.byref(nb)) != 0:
+        raise RuntimeError(f"cannot read {path}")
+    out = np.empty((h.value, w.value, nb.value), np.float32)
+    lib.mpmvs_host_read_dmb(str(path).encode(), out.ctypes.data, out.size, C.byref(h), C.byref(w), C.byref(nb))
+    return out[..., 0] if nb.value == 1 else out
+
+
+def read_camera(path):
+    cam = _abi.Camera()
+    load().mpmvs_host_read_camera(str(path).encode(), C.byref(cam))
+    return cam
+
+
+def sample_list(folder, max_src=20, max_size=3200):
+    """pair.txt -> list of (estimate, refID, srcID list with srcID[0] == refID)"""
+    lib = load()
+    n = lib.mpmvs_host_sample_list(str(folder).encode(), max_src, max_size, None, 0)
+    buf = np.empty(n, np.int32)
+    lib.mpmvs_host_sample_list(str(folder).encode(), max_src, max_size, buf.ctypes.data, n)
+    out, k = [], 1
+    for _ in range(int(buf[0])):
+        est, ref, cnt = int(buf[k]), int(buf[k + 1]), int(buf[k + 2])
+        out.append((bool(est), ref, [int(v) for v in buf[k + 3:k + 3 + cnt]]))
+        k += 3 + cnt
+    return out
+
+
+def read_pgm(path):
+    lib = load()
+    h, w = C.c_int(), C.c_int()
+    if lib.mpmvs_host_read_pgm(str(path).encode(), None, 0, C.byref(h), C.byref(w)) != 0:
+        raise RuntimeError(f"cannot read {path}")
+    out = np.empty((h.value, w.value), np.float32)
+    lib.mpmvs_host_read_pgm(str(path).encode(), out.ctypes.data, out.size, C.byref(h), C.byref(w))
+    return out
+
+
+def run_folder(folder, device=0, max_src=20, geom_iterations=2, planar_prior=True, geom_planar_prior=True, max_scale=2, seed=12345):
+    rc = load().mpmvs_host_run_folder(str(folder).encode(), device, max_src, geom_iterations, 1 if planar_prior else 0,
+                                      1 if geom_planar_prior else 0, max_scale, seed)
+    if rc != 0:
+        raise RuntimeError(f"run_folder failed ({rc})")
+
+
+def write_dataset(folder, cams, images, sources, scores=None):
+    """a scene in the reference's input layout: images/%08d.pgm, cams/%08d_cam.txt
+    (MVSNet style, reference src/PatchMatch.cpp:109-143), pair.txt (reference :67-107)"""
+    import os
+    os.makedirs(os.path.join(folder, "images"), exist_ok=True)
+    os.makedirs(os.path.join(folder, "cams"), exist_ok=True)
+    for i, (cam, img) in enumerate(zip(cams, images)):
+        a = np.asarray(img)
+        assert np.array_equal(a, np.rint(a)) and a.min() >= 0 and a.max() <= 255, "PGM holds 8-bit images"
+        with open(os.path.join(folder, "images", f"{i:08d}.pgm"), "wb") as f:
+            f.write(b"P5\n%d %d\n255\n" % (a.shape[1], a.shape[0]))
+            f.write(a.astype(np.uint8).tobytes())
+        R, t, K = list(cam.R), list(cam.t), list(cam.K)
+        with open(os.path.join(folder, "cams", f"{i:08d}_cam.txt"), "w") as f:
+            f.write("extrinsic\n")
+            for r in range(3):
+                f.write(" ".join(repr(float(np.float32(v))) for v in (R[3 * r], R[3 * r + 1], R[3 * r + 2], t[r])) + "\n")
+            f.write("0.0 0.0 0.0 1.0\n\nintrinsic\n")
+            for r in range(3):
+                f.write(" ".join(repr(float(np.float32(v))) for v in K[3 * r:3 * r + 3]) + "\n")
+            f.write(f"\n{float(np.float32(cam.depth_min))!r} 0.01 192 {float(np.float32(cam.depth_max))!r}\n")
+    with open(os.path.join(folder, "pair.txt"), "w") as f:
+        f.write(f"{len(sources)}\n")
+        for i, src in enumerate(sources):
+            sc = scores[i] if scores is not None else [100.0 - k for k in range(len(src))]
+            f.write(f"{i}\n{len(src)} " + " ".join(f"{s} {v}" for s, v in zip(src, sc)) + "\n")

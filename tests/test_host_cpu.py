@@ -154,3 +154,40 @@ def test_build_prior_recovers_a_plane(pm, hostlib):
     # a depth range that excludes the plane clears the mask (reference :583-595)
     _, mask2, _ = hostlib.build_prior(cam, planes, costs, None, False, 10.0, 20.0)
     assert mask2.max() == 0
+
+
+# ---------------------------------------------------------------------------
+# file formats
+# ---------------------------------------------------------------------------
+def test_dmb_round_trip_and_layout(hostlib, tmp_path):
+    rng = np.random.default_rng(0)
+    d = rng.uniform(0, 9, (7, 11)).astype(np.float32)
+    n = rng.normal(size=(7, 11, 3)).astype(np.float32)
+    hostlib.write_dmb(tmp_path / "d.dmb", d)
+    hostlib.write_dmb(tmp_path / "n.dmb", n)
+    raw = open(tmp_path / "n.dmb", "rb").read()
+    assert np.frombuffer(raw[:16], np.int32).tolist() == [1, 7, 11, 3]      # type, h, w, nb (reference utility.cpp:287-296)
+    assert np.array_equal(np.frombuffer(raw[16:], np.float32).reshape(7, 11, 3), n)
+    assert np.array_equal(hostlib.read_dmb(tmp_path / "d.dmb"), d) and np.array_equal(hostlib.read_dmb(tmp_path / "n.dmb"), n)
+    open(tmp_path / "bad.dmb", "wb").write(np.array([2, 7, 11, 1], np.int32).tobytes() + d.tobytes())
+    with pytest.raises(RuntimeError):
+        hostlib.read_dmb(tmp_path / "bad.dmb")                                 # type != 1 is rejected (reference :213-216)
+
+
+def test_camera_pair_and_image_files(pm, hostlib, tmp_path):
+    sc, neigh = pm.synth.make_grid_scene(40, 30, 3, 2, spacing=0.5, quantize=True)
+    cams = [v.cam for v in sc.views]
+    imgs = [v.image for v in sc.views]
+    scores = [[50.0 - k for k in range(len(s))] for s in neigh]
+    scores[1][2] = 0.0                                                         # score <= 0 is dropped (reference PatchMatch.cpp:98-100)
+    hostlib.write_dataset(str(tmp_path), cams, imgs, neigh, scores)
+    for i, cam in enumerate(cams):
+        got = hostlib.read_camera(tmp_path / "cams" / f"{i:08d}_cam.txt")
+        assert list(got.K) == list(cam.K) and list(got.R) == list(cam.R) and list(got.t) == list(cam.t)
+        assert np.allclose(list(got.C), list(cam.C), atol=1e-6)               # C = -R^T t recomputed in fp32 (reference :134-136)
+        assert (got.depth_min, got.depth_max) == (cam.depth_min, cam.depth_max)
+        assert np.array_equal(hostlib.read_pgm(tmp_path / "images" / f"{i:08d}.pgm"), imgs[i])
+    lst = hostlib.sample_list(tmp_path, max_src=3)
+    assert len(lst) == 6 and all(e for e, _, _ in lst)
+    assert lst[0][2] == [0] + neigh[0][:3]                                     # at most `Max source images num` kept
+    assert lst[1][2] == [1] + [s for k, s in enumerate(neigh[1][:3]) if k != 2]

@@ -76,3 +76,54 @@ def test_scheduler_device_exchange_bit_exact(pm, oracle, engine):
     assert np.array_equal(gpu.all_depths.cpu().numpy(), cpu.all_depths)
     for i in range(6):
         assert np.array_equal(rg[i][0], rc[i][0]) and np.array_equal(rg[i][1], rc[i][1]), f"problem {i}"
+
+
+def test_folder_pipeline_matches_oracle(pm, oracle, engine, tmp_path):
+    """the reference's file-based flow (src/main.cpp:20-41 over pair.txt / cams / images,
+    results exchanged through depths/normals/costs.dmb, sequential and in place) on the HIP
+    path == the same sequence driven on the oracle in memory"""
+    hostlib = importlib.import_module("mp-mvs_amd.hostlib")
+    sc, neigh = pm.synth.make_grid_scene(64, 48, 3, 2, spacing=0.5, rot_deg=1.0, quantize=True)
+    cams = [v.cam for v in sc.views]
+    imgs = [v.image for v in sc.views]
+    hostlib.write_dataset(str(tmp_path), cams, imgs, neigh)
+    SEED, GEOM_IT, MAX_SCALE = 31337, 2, 1
+    hostlib.run_folder(tmp_path, device=0, geom_iterations=GEOM_IT, planar_prior=True, geom_planar_prior=True, max_scale=MAX_SCALE, seed=SEED)
+
+    # oracle replica (Gauss-Seidel: Problem i+1 already sees Problem i's new depth map)
+    state = {}
+    handles = {}
+    for i in range(6):
+        h = oracle.create()
+        ids = [i] + neigh[i]
+        h.set_views([cams[j] for j in ids], [imgs[j] for j in ids])
+        handles[i] = h
+
+    def process(i, geom, planar, seed):
+        h = handles[i]
+        dmin, dmax = pm.synth.kernel_depth_range(cams[i])
+        p = pm.PatchMatchParams(num_images=1 + len(neigh[i]), depth_min=float(dmin), depth_max=float(dmax), max_scale=MAX_SCALE)
+        p.geom_consistency, p.max_iterations, p.geomPlanarPrior = geom, (2 if geom else 3), bool(geom and planar)
+        if geom:
+            h.set_src_depths([state[j][0][..., 3] for j in neigh[i]])
+            h.set_state(state[i][0], state[i][1])
+        h.run(p, seed)
+        if planar:
+            planes, costs, g = h.get(geom=True)
+            gpp = bool(p.geomPlanarPrior)
+            prior, mask, ntri = hostlib.build_prior(cams[i], planes, costs, g if gpp else None, gpp, p.depth_min, p.depth_max)
+            h.set_prior(prior, mask)
+            p.planar_prior, p.geom_consistency, p.max_iterations = True, False, 3
+            h.run(p, (seed + PRIOR_SEED_OFFSET) & 0xFFFFFFFFFFFFFFFF)
+        state[i] = h.get()
+
+    for i in range(6):
+        process(i, False, False, SEED + i)
+    for g in range(GEOM_IT):
+        for i in range(6):
+            process(i, True, g != GEOM_IT - 1, SEED + 100003 * (g + 1) + i)
+    for i in range(6):
+        d = tmp_path / "MPMVS" / f"2333_{i:08d}"
+        assert np.array_equal(hostlib.read_dmb(d / "depths.dmb"), state[i][0][..., 3]), f"depths of image {i}"
+        assert np.array_equal(hostlib.read_dmb(d / "normals.dmb"), state[i][0][..., :3]), f"normals of image {i}"
+        assert np.array_equal(hostlib.read_dmb(d / "costs.dmb"), state[i][1]), f"costs of image {i}"
