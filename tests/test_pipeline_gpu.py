@@ -89,6 +89,14 @@ def test_folder_pipeline_matches_oracle(pm, oracle, engine, tmp_path):
     hostlib.write_dataset(str(tmp_path), cams, imgs, neigh)
     SEED, GEOM_IT, MAX_SCALE = 31337, 2, 1
     hostlib.run_folder(tmp_path, device=0, geom_iterations=GEOM_IT, planar_prior=True, geom_planar_prior=True, max_scale=MAX_SCALE, seed=SEED)
+    # the pipeline works from the files: ReadCamera recomputes C = -R^T t in fp32
+    # (reference src/PatchMatch.cpp:134-136), so the replica must use the cameras as parsed
+    file_cams = []
+    for i in range(6):
+        c = hostlib.read_camera(tmp_path / "cams" / f"{i:08d}_cam.txt")
+        c.height, c.width = imgs[i].shape
+        file_cams.append(c)
+    cams = file_cams
 
     # oracle replica (Gauss-Seidel: Problem i+1 already sees Problem i's new depth map)
     state = {}
