@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path on one GPU)")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--float-images", action="store_true",
                     help="keep the rendered images as non-integer fp32 (rescaled-image case) instead of 8-bit camera-like images")
     args = ap.parse_args()
@@ -130,12 +133,14 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     dist = None
+    dev_index = 0 if args.share_device else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
 
     pm = importlib.import_module("mp-mvs_amd")
     engine = importlib.import_module("mp-mvs_amd.engine")
@@ -144,7 +149,7 @@ def main():
     cams, imgs, gt = load_scene(pm, W, H, V, quantize)
     dmin, dmax = pm.synth.kernel_depth_range(cams[0])
     prm = pm.PatchMatchParams(num_images=V + 1, depth_min=float(dmin), depth_max=float(dmax), max_scale=0, max_iterations=ITERS)
-    ctx = engine.create(local_rank)
+    ctx = engine.create(dev_index)
     ctx.set_views(cams, imgs)   # inputs resident in HBM from here on
     ctx.set_profiling(True)
     seed = 12345 + rank
@@ -168,7 +173,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
