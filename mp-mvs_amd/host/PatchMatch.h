@@ -94,6 +94,9 @@ struct Scene {
     int max_image_size = 3200;
 };
 
+// bilinear resize used by PatchMatchInit's "Adjust image scale" (reference src/PatchMatch.cpp:893-925)
+Image ResizeLinear(const Image& src, int new_cols, int new_rows);
+
 class PatchMatchCUDA {
    private:
     int num_img = 0;

@@ -3,6 +3,7 @@
 // include/mpmvs.h.  Error convention of the reference is kept here: print and
 // exit(EXIT_FAILURE) (reference src/PatchMatch.cpp:60-65); the C ABI underneath
 // never exits.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -11,6 +12,35 @@
 #include <iostream>
 
 #include "PatchMatch.h"
+
+// cv::resize(src, dst, Size(new_cols, new_rows), 0, 0, INTER_LINEAR) for a 1-channel fp32
+// image: sample position (x + 0.5) * (src/dst) - 0.5, edge texels replicated.
+// OpenCV is absent here, so this follows its documented geometry; the last-bit
+// behaviour of its SIMD kernels is "parity unpinned" (SURVEY 8c).
+Image ResizeLinear(const Image& src, int new_cols, int new_rows) {
+    Image dst(new_rows, new_cols, 1);
+    const float sx = (float)src.cols / new_cols, sy = (float)src.rows / new_rows;
+    for (int y = 0; y < new_rows; ++y) {
+        float fy = (y + 0.5f) * sy - 0.5f;
+        int y0 = (int)std::floor(fy);
+        float ay = fy - y0;
+        if (y0 < 0) { y0 = 0; ay = 0.0f; }
+        if (y0 >= src.rows - 1) { y0 = src.rows - 1; ay = 0.0f; }
+        const int y1 = std::min(y0 + 1, src.rows - 1);
+        for (int x = 0; x < new_cols; ++x) {
+            float fx = (x + 0.5f) * sx - 0.5f;
+            int x0 = (int)std::floor(fx);
+            float ax = fx - x0;
+            if (x0 < 0) { x0 = 0; ax = 0.0f; }
+            if (x0 >= src.cols - 1) { x0 = src.cols - 1; ax = 0.0f; }
+            const int x1 = std::min(x0 + 1, src.cols - 1);
+            const float top = src.at(y0, x0) + ax * (src.at(y0, x1) - src.at(y0, x0));
+            const float bot = src.at(y1, x0) + ax * (src.at(y1, x1) - src.at(y1, x0));
+            dst.at(y, x) = top + ay * (bot - top);
+        }
+    }
+    return dst;
+}
 
 void PatchMatchCUDA::check(int rc, const char* what) {
     if (rc != 0) {
@@ -59,6 +89,28 @@ void PatchMatchCUDA::PatchMatchInit(std::vector<Scene>& Scenes, const int ID) {
         cam.height = s.image.rows;
         cam.width = s.image.cols;
         cameras.push_back(cam);
+    }
+    // Adjust image scale (reference src/PatchMatch.cpp:893-925): images larger than
+    // max_image_size are shrunk with bilinear interpolation and K follows
+    for (int i = 0; i < num_img; ++i) {
+        Scene& s = Scenes[srcID[i]];
+        const int max_image_size = s.max_image_size;
+        if (s.image.cols <= max_image_size && s.image.rows <= max_image_size) continue;
+        const float factor_x = static_cast<float>(max_image_size) / s.image.cols;
+        const float factor_y = static_cast<float>(max_image_size) / s.image.rows;
+        const float factor = std::min(factor_x, factor_y);
+        const int new_cols = (int)std::round(s.image.cols * factor);
+        const int new_rows = (int)std::round(s.image.rows * factor);
+        const float scale_x = new_cols / static_cast<float>(s.image.cols);
+        const float scale_y = new_rows / static_cast<float>(s.image.rows);
+        s.image = ResizeLinear(s.image, new_cols, new_rows);
+        images[i] = &s.image;
+        cameras[i].K[0] *= scale_x;
+        cameras[i].K[2] *= scale_x;
+        cameras[i].K[4] *= scale_y;
+        cameras[i].K[5] *= scale_y;
+        cameras[i].height = new_rows;
+        cameras[i].width = new_cols;
     }
     params.depth_min = cameras[0].depth_min * 0.6f;  // reference :929-930
     params.depth_max = cameras[0].depth_max * 1.2f;
@@ -295,6 +347,15 @@ int mpmvs_host_build_prior(const mpmvs_camera* cam, int w, int h, const float* p
             std::memcpy(prior4 + 4 * idx, &o, 16);
         }
     return (int)pp.size();
+}
+
+// bilinear resize probe (ResizeLinear)
+int mpmvs_host_resize_linear(const float* src, int w, int h, float* dst, int new_w, int new_h) {
+    Image s(h, w, 1);
+    std::memcpy(s.data.data(), src, s.data.size() * sizeof(float));
+    const Image d = ResizeLinear(s, new_w, new_h);
+    std::memcpy(dst, d.data.data(), d.data.size() * sizeof(float));
+    return 0;
 }
 
 // One Problem through the reference's pass schedule (src/main.cpp:20-41) with the

@@ -191,3 +191,18 @@ def test_camera_pair_and_image_files(pm, hostlib, tmp_path):
     assert len(lst) == 6 and all(e for e, _, _ in lst)
     assert lst[0][2] == [0] + neigh[0][:3]                                     # at most `Max source images num` kept
     assert lst[1][2] == [1] + [s for k, s in enumerate(neigh[1][:3]) if k != 2]
+
+
+def test_resize_linear_geometry(hostlib):
+    """INTER_LINEAR geometry (reference src/PatchMatch.cpp:915): a linear ramp stays the same
+    ramp under resampling (sampled at (x+0.5)*scale-0.5), constants stay constant, 2x
+    shrink of an even image averages 2x2 blocks"""
+    x = np.arange(40, dtype=np.float32)[None, :].repeat(30, 0)
+    out = hostlib.resize_linear(x, 20, 15)
+    assert np.allclose(out, ((np.arange(20) + 0.5) * 2 - 0.5)[None, :], atol=1e-5)
+    assert np.all(hostlib.resize_linear(np.full((30, 40), 7.5, np.float32), 13, 11) == 7.5)
+    rng = np.random.default_rng(0)
+    img = rng.uniform(0, 255, (30, 40)).astype(np.float32)
+    half = hostlib.resize_linear(img, 20, 15)
+    assert np.allclose(half, img.reshape(15, 2, 20, 2).mean((1, 3)), atol=1e-3)
+    assert np.array_equal(hostlib.resize_linear(img, 40, 30), img)
