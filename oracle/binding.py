@@ -29,6 +29,8 @@ def lib():
         fns = _abi.bind(l, "orc_")
         l.orc_create.restype = C.c_void_p
         l.orc_create.argtypes = []
+        l.orc_eval_ncc_literal.restype = C.c_int
+        l.orc_eval_ncc_literal.argtypes = [C.c_void_p, C.POINTER(_abi.PatchMatchParams), C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         l.orc_num_threads.restype = C.c_int
         l.orc_set_num_threads.argtypes = [C.c_int]
         _cache["lib"] = l
@@ -51,3 +53,15 @@ def num_threads():
 
 def set_num_threads(n):
     lib()[0].orc_set_num_threads(int(n))
+
+
+def eval_ncc_literal(handle, params, planes_cam, scale, quantize_fraction=False):
+    """NCC in the reference's literal operation order (see pm_oracle.cpp); measurement only"""
+    import numpy as np
+    l, _ = lib()
+    p = np.ascontiguousarray(planes_cam, np.float32)
+    out = np.empty((params.num_images - 1, handle.H, handle.W), np.float32)
+    rc = l.orc_eval_ncc_literal(handle._ctx, C.byref(params), p.ctypes.data, int(scale), 1 if quantize_fraction else 0, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"orc_eval_ncc_literal failed ({rc})")
+    return out
