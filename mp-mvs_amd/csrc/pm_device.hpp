@@ -292,9 +292,11 @@ PM_DEV void load_ref_tile(const ProblemDev& P, float* tile, int x0, int y0, int 
     }
 }
 
-// weights of pixel (px,py) -> LDS column `lw`; (lx,ly) = position inside the block
-PM_DEV void ref_window(float4* lw, const float* tile, int tpitch, int lx, int ly, int step, int radius, float two_ss, float two_sc, RefWin& rw) {
-    const float* ctr = tile + (ly + radius) * tpitch + (lx + radius);
+// weights of one pixel -> LDS column `lw`.  `ctr` points at the pixel in a reference
+// image with pitch `tpitch` whose window taps are all addressable: the block's LDS
+// tile, or (when the tile would not leave room for two blocks per CU) the
+// apron-padded image in global memory.
+PM_DEV void ref_window(float4* lw, const float* ctr, int tpitch, int step, int radius, float two_ss, float two_sc, RefWin& rw) {
     const float rc = ctr[0];
     float sw = 0.0f, swr = 0.0f, swrr = 0.0f;
 #pragma unroll

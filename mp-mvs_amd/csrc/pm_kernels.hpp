@@ -98,9 +98,27 @@ PM_DEV bool dense_pixel(const ProblemDev& P, int& x, int& y) {
 // dynamic LDS of the NCC kernels: 18 float4 weight records per thread + the reference tile
 extern __shared__ float pm_lds[];
 constexpr int kLdsWeightFloats = 2 * 36 * kBlockThreads;
+// The reference tile is staged in LDS only while two blocks still fit a CU's 160 KB
+// (scales 0 and 1: 4.4 / 7.5 KB).  At scale 2 (16 KB) it would halve the occupancy
+// of the whole kernel for the sake of the prologue (measured 5.96 vs 3.9 ms per
+// launch), so the window is read from the L2-resident padded image instead.
+__host__ __device__ inline bool use_ref_tile(int scale) { return scale < 2; }
 inline size_t ncc_lds_bytes(int bw, int bh, int scale) {
     const int radius = 5 * (2 << scale) / 2;
-    return (size_t)(kLdsWeightFloats + (bw + 2 * radius) * (bh + 2 * radius)) * sizeof(float);
+    const int tile = use_ref_tile(scale) ? (bw + 2 * radius) * (bh + 2 * radius) : 0;
+    return (size_t)(kLdsWeightFloats + tile) * sizeof(float);
+}
+// pointer to pixel (x, y) with all its window taps addressable, and its pitch
+PM_DEV const float* ref_center(const ProblemDev& P, float* tile, int x, int y, int x0, int y0, int bw, int bh, int radius, int scale, int& pitch) {
+    if (use_ref_tile(scale)) {
+        load_ref_tile(P, tile, x0, y0, bw, bh, radius);
+        __syncthreads();
+        pitch = bw + 2 * radius;
+        return tile + (y - y0 + radius) * pitch + (x - x0 + radius);
+    }
+    pitch = P.ref_pitch;
+    const int cx = x < P.W ? x : P.W - 1, cy = y < P.H ? y : P.H - 1;  // threads outside the image never use it
+    return P.ref_img + (long)cy * P.ref_pitch + cx;
 }
 
 // ---------------------------------------------------------------------------
@@ -112,16 +130,14 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_init(const ProblemDe
     int x, y, x0, y0;
     const bool valid = dense_pixel(P, x, y, x0, y0);
     const int step = 2 << a.scale, radius = 5 * step / 2;
-    float* tile = pm_lds + kLdsWeightFloats;
-    const int tpitch = 16 + 2 * radius;
-    load_ref_tile(P, tile, x0, y0, 16, 16, radius);
-    __syncthreads();
+    int tpitch;
+    const float* ctr = ref_center(P, pm_lds + kLdsWeightFloats, x, y, x0, y0, 16, 16, radius, a.scale, tpitch);
     if (!valid) return;
     const int idx = y * P.W + x;
     const int V = P.V;
     Rng g = rng_make(a.seed, (uint32_t)idx, a.launch);
     RefWin rw;
-    ref_window((float4*)pm_lds + threadIdx.x, tile, tpitch, x - x0, y - y0, step, radius, a.two_ss, a.two_sc, rw);
+    ref_window((float4*)pm_lds + threadIdx.x, ctr, tpitch, step, radius, a.two_ss, a.two_sc, rw);
 
     float4 pl;
     if (a.init_random) {
@@ -192,16 +208,14 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
     int x, y, x0, y0;
     const bool valid = checker_pixel(P, a, x, y, x0, y0);
     const int step = 2 << a.scale, radius = 5 * step / 2;
-    float* tile = pm_lds + kLdsWeightFloats;
-    const int tpitch = kChkBlockW + 2 * radius;
-    load_ref_tile(P, tile, x0, y0, kChkBlockW, kChkBlockH, radius);
-    __syncthreads();
+    int tpitch;
+    const float* ctr = ref_center(P, pm_lds + kLdsWeightFloats, x, y, x0, y0, kChkBlockW, kChkBlockH, radius, a.scale, tpitch);
     if (!valid) return;
     const int W = P.W, Hh = P.H, V = P.V;
     const int idx = y * W + x;
     Rng g = rng_make(a.seed, (uint32_t)idx, a.launch);
     RefWin rw;
-    ref_window((float4*)pm_lds + threadIdx.x, tile, tpitch, x - x0, y - y0, step, radius, a.two_ss, a.two_sc, rw);
+    ref_window((float4*)pm_lds + threadIdx.x, ctr, tpitch, step, radius, a.two_ss, a.two_sc, rw);
 
     // -- 8 sampling regions: position of the lowest stored cost (ref .cu:798-816)
     int pos[8];
@@ -588,14 +602,12 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_eval_ncc(const Probl
     int x, y, x0, y0;
     const bool valid = dense_pixel(P, x, y, x0, y0);
     const int step = 2 << a.scale, radius = 5 * step / 2;
-    float* tile = pm_lds + kLdsWeightFloats;
-    const int tpitch = 16 + 2 * radius;
-    load_ref_tile(P, tile, x0, y0, 16, 16, radius);
-    __syncthreads();
+    int tpitch;
+    const float* ctr = ref_center(P, pm_lds + kLdsWeightFloats, x, y, x0, y0, 16, 16, radius, a.scale, tpitch);
     if (!valid) return;
     const int idx = y * P.W + x;
     RefWin rw;
-    ref_window((float4*)pm_lds + threadIdx.x, tile, tpitch, x - x0, y - y0, step, radius, a.two_ss, a.two_sc, rw);
+    ref_window((float4*)pm_lds + threadIdx.x, ctr, tpitch, step, radius, a.two_ss, a.two_sc, rw);
     float m0, m1, m2;
     plane_to_m(P, planes[idx], m0, m1, m2);
     const long wh = (long)P.W * P.H;
