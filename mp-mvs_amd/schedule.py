@@ -31,13 +31,18 @@ def owned_problems(n_problems, rank, world):
 
 
 class SceneScheduler:
-    def __init__(self, cams, images, sources, make_handle, rank=0, world=1, dist=None, device_tensors=False, max_scale=2):
+    def __init__(self, cams, images, sources, make_handle, rank=0, world=1, dist=None, device_tensors=False, max_scale=2, workers=1):
         """cams/images: all views of the scene; sources[i]: source-view ids of Problem i;
-        make_handle(): a fresh PatchMatch handle (engine.create(local_rank) in production)."""
+        make_handle(): a fresh PatchMatch handle (engine.create(local_rank) in production);
+        workers: host threads per rank.  Within a pass the owned Problems are independent, so with
+        workers > 1 the host half of one Problem (planar-prior construction, transfers) overlaps the
+        kernels of others -- every context has its own stream and the C calls release the GIL.
+        Results do not depend on the interleaving."""
         self.cams, self.images, self.sources = cams, images, sources
         self.n = len(sources)
         self.rank, self.world, self.dist = rank, world, dist
         self.max_scale = max_scale
+        self.workers = max(1, int(workers))
         self.owned = owned_problems(self.n, rank, world)
         self.per_rank = (self.n + world - 1) // world
         self.H, self.W = images[0].shape
@@ -130,14 +135,18 @@ class SceneScheduler:
     # -- the pass schedule of reference src/main.cpp:20-41 ----------------------
     def run(self, geom_iterations=2, planar_prior=True, geom_planar_prior=True, seed=12345):
         planar0 = (not geom_planar_prior) and planar_prior
-        for i in self.owned:
-            self.results[i] = self._process(i, False, planar0, seed + i)
+        self.results = self._pass(lambda i: self._process(i, False, planar0, seed + i))
         self._exchange()
         for g in range(geom_iterations):
             planar = bool(geom_planar_prior and g != geom_iterations - 1)
-            new = {}
-            for i in self.owned:
-                new[i] = self._process(i, True, planar, seed + 100003 * (g + 1) + i)
-            self.results = new          # Jacobi: nothing of pass g was visible during pass g
+            # Jacobi: nothing of pass g is visible during pass g (results swapped afterwards)
+            self.results = self._pass(lambda i, g=g, planar=planar: self._process(i, True, planar, seed + 100003 * (g + 1) + i))
             self._exchange()
         return self.results
+
+    def _pass(self, fn):
+        if self.workers == 1 or len(self.owned) <= 1:
+            return {i: fn(i) for i in self.owned}
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=self.workers) as pool:
+            return dict(zip(self.owned, pool.map(fn, self.owned)))

@@ -76,6 +76,11 @@ def test_scheduler_device_exchange_bit_exact(pm, oracle, engine):
     assert np.array_equal(gpu.all_depths.cpu().numpy(), cpu.all_depths)
     for i in range(6):
         assert np.array_equal(rg[i][0], rc[i][0]) and np.array_equal(rg[i][1], rc[i][1]), f"problem {i}"
+    # worker threads overlap host and device work of different Problems; same bits
+    gpu3 = sched.SceneScheduler(cams, imgs, neigh, lambda: engine.create(0), device_tensors=True, max_scale=1, workers=3)
+    r3 = gpu3.run(**kw)
+    for i in range(6):
+        assert np.array_equal(r3[i][0], rc[i][0]) and np.array_equal(r3[i][1], rc[i][1]), f"problem {i} (3 workers)"
 
 
 def test_folder_pipeline_matches_oracle(pm, oracle, engine, tmp_path):

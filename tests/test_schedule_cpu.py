@@ -25,7 +25,7 @@ def _run(rank, world, dist, kw):
     sched = importlib.import_module("mp-mvs_amd.schedule")
     ob.set_num_threads(2)
     cams, imgs, neigh = _scene()
-    s = sched.SceneScheduler(cams, imgs, neigh, ob.create, rank=rank, world=world, dist=dist, max_scale=0)
+    s = sched.SceneScheduler(cams, imgs, neigh, ob.create, rank=rank, world=world, dist=dist, max_scale=0, workers=2 if world > 1 else 1)
     res = s.run(**kw)
     return {i: (r[0], r[1]) for i, r in res.items()}, s.all_depths
 
