@@ -150,6 +150,20 @@ int mpmvs_math(int fn, const void* in, void* out, int n);
 /* first n uniforms of RNG stream (seed, pixel, launch_id) */
 int mpmvs_rng(uint64_t seed, uint32_t pix, uint32_t launch_id, int n, void* out);
 
+/* ---- depth-map fusion ---------------------------------------- */
+/* RunFusion's per-pixel consistency check and averaging (src/PatchMatch.cpp:287-504) in
+ * the deterministic "snapshot" formulation of DESIGN.md section 8.  Image k has
+ * cams[k] (width/height = size of its maps), depths[k] (fp32), normals[k] (3 fp32 per
+ * pixel, world frame), gray[k] (fp32 intensity used as colour), estimate[k] (0 = skip),
+ * and the view list src_ids[src_off[k] .. src_off[k+1]) whose first entry is k itself
+ * (Scene::srcID).  Outputs per image: out_valid (1 where a fused point was produced),
+ * out_points9 (x y z nx ny nz r g b per pixel), out_masks (pixels consumed by points of
+ * other images).  Host buffers in and out. */
+int mpmvs_fuse(int device, int n, const mpmvs_camera* cams, const int* estimate, const float* const* depths,
+               const float* const* normals, const float* const* gray, const int* src_off, const int* src_ids,
+               int use_dynamic_consistency, unsigned char* const* out_valid, float* const* out_points9,
+               unsigned char* const* out_masks);
+
 /* ---- resident texture format ---------------------------------------------- */
 /* Source images whose pixels are all integers in [0, 255] (the reference's
  * imread(GRAYSCALE) -> convertTo(CV_32F) path, src/PatchMatch.cpp:877-882) are

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/mpmvs.h"
+#include "pm_fusion.hpp"
 #include "pm_kernels.hpp"
 
 using namespace pm;
@@ -683,6 +684,80 @@ int mpmvs_rng(uint64_t seed, uint32_t pix, uint32_t launch_id, int n, void* out)
     if (hipGetLastError() != hipSuccess) rc = -100;
     if (!rc && hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = -100;
     (void)hipFree(d_out);
+    return rc;
+}
+
+// depth-map fusion, snapshot formulation (pm_fusion.hpp); host buffers in and out
+int mpmvs_fuse(int device, int n, const mpmvs_camera* cams, const int* estimate, const float* const* depths, const float* const* normals,
+               const float* const* gray, const int* src_off, const int* src_ids, int use_dynamic, unsigned char* const* out_valid,
+               float* const* out_points9, unsigned char* const* out_masks) {
+    if (n <= 0 || hipSetDevice(device) != hipSuccess) return -1;
+    std::vector<FuseView> hv(n);
+    std::vector<void*> to_free;
+    auto dalloc = [&](size_t bytes) -> void* {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return nullptr;
+        to_free.push_back(p);
+        return p;
+    };
+    int rc = 0;
+    std::vector<unsigned char*> d_valid(n, nullptr);
+    std::vector<float*> d_out(n, nullptr);
+    std::vector<unsigned char*> d_mask(n, nullptr), d_next(n, nullptr);
+    for (int i = 0; i < n && !rc; ++i) {
+        const size_t wh = (size_t)cams[i].width * cams[i].height;
+        FuseView& v = hv[i];
+        cam_to_dev(cams[i], v.cam);
+        v.w = cams[i].width;
+        v.h = cams[i].height;
+        float* dd = (float*)dalloc(wh * 4);
+        float* dn = (float*)dalloc(wh * 12);
+        float* dg = (float*)dalloc(wh * 4);
+        d_mask[i] = (unsigned char*)dalloc(wh);
+        d_next[i] = (unsigned char*)dalloc(wh);
+        d_valid[i] = (unsigned char*)dalloc(wh);
+        d_out[i] = (float*)dalloc(wh * 36);
+        if (!dd || !dn || !dg || !d_mask[i] || !d_next[i] || !d_valid[i] || !d_out[i]) { rc = -100; break; }
+        if (hipMemcpy(dd, depths[i], wh * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dn, normals[i], wh * 12, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(dg, gray[i], wh * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemset(d_mask[i], 0, wh) != hipSuccess ||
+            hipMemset(d_next[i], 0, wh) != hipSuccess || hipMemset(d_valid[i], 0, wh) != hipSuccess || hipMemset(d_out[i], 0, wh * 36) != hipSuccess)
+            rc = -100;
+        v.depth = dd;
+        v.normal = dn;
+        v.gray = dg;
+        v.mask = d_mask[i];
+        v.mask_next = d_next[i];
+    }
+    FuseView* d_views = nullptr;
+    int* d_src = nullptr;
+    if (!rc) {
+        d_views = (FuseView*)dalloc(sizeof(FuseView) * n);
+        d_src = (int*)dalloc(sizeof(int) * (src_off[n] > 0 ? src_off[n] : 1));
+        if (!d_views || !d_src || hipMemcpy(d_views, hv.data(), sizeof(FuseView) * n, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_src, src_ids, sizeof(int) * src_off[n], hipMemcpyHostToDevice) != hipSuccess)
+            rc = -100;
+    }
+    for (int i = 0; i < n && !rc; ++i) {
+        if (!estimate[i]) continue;
+        const int b = src_off[i], num_ngb = src_off[i + 1] - b;
+        if (num_ngb > kMaxFuseNgb) { rc = -2; break; }
+        const dim3 grid((hv[i].w + 31) / 32, (hv[i].h + 7) / 8);
+        hipLaunchKernelGGL(k_fuse, grid, dim3(256), 0, nullptr, d_views, i, d_src + b, num_ngb, use_dynamic, d_valid[i], d_out[i]);
+        if (hipGetLastError() != hipSuccess) { rc = -100; break; }
+        // the marks of image i become the masks the next image sees
+        for (int j = 1; j < num_ngb; ++j) {
+            const int s = src_ids[b + j];
+            if (hipMemcpyAsync(d_mask[s], d_next[s], (size_t)hv[s].w * hv[s].h, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) rc = -100;
+        }
+    }
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -100;
+    for (int i = 0; i < n && !rc; ++i) {
+        const size_t wh = (size_t)hv[i].w * hv[i].h;
+        if (hipMemcpy(out_valid[i], d_valid[i], wh, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(out_points9[i], d_out[i], wh * 36, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(out_masks[i], d_mask[i], wh, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = -100;
+    }
+    for (void* p : to_free) (void)hipFree(p);
     return rc;
 }
 

@@ -1,0 +1,127 @@
+// pm_fusion.hpp -- depth-map fusion on the GPU: the consumer of the
+// hot path's depth/normal maps (reference RunFusion, src/PatchMatch.cpp:287-504).
+//
+// The reference fuses sequentially: every accepted point masks the source pixels it
+// used, and later pixels / images skip masked pixels, so its result depends on raster
+// order (and on a used_list that is never reset between pixels).  That cannot run in
+// parallel.  This kernel implements the "snapshot" formulation of DESIGN.md section 8:
+// images are still fused in index order, but all pixels of one image read the masks as
+// they were when the image started; the masks it produces become visible to the next
+// image.  One thread = one pixel; HBM-bound (per pixel: own depth/normal/colour plus,
+// per source view, one mask byte, one depth, one normal, one colour).
+#pragma once
+
+#include "pm_device.hpp"
+
+namespace pm {
+
+struct FuseView {
+    CamDev cam;
+    int w, h;
+    const float* depth;
+    const float* normal;  // 3 floats per pixel (world)
+    const float* gray;
+    const unsigned char* mask;  // snapshot read by the kernel
+    unsigned char* mask_next;   // marks written by the kernel
+};
+
+// reference src/PatchMatch.cpp:211-231
+PM_DEV void point_on_world(const CamDev& cam, int x, int y, float depth, float& o0, float& o1, float& o2) {
+    backproject(cam, (float)x, (float)y, depth, o0, o1, o2);
+}
+// reference src/PatchMatch.cpp:251-261
+PM_DEV void project_depth(const CamDev& cam, float p0, float p1, float p2, float& u, float& v, float& depth) {
+    const float t0 = ((cam.R[0] * p0 + cam.R[1] * p1) + cam.R[2] * p2) + cam.t[0];
+    const float t1 = ((cam.R[3] * p0 + cam.R[4] * p1) + cam.R[5] * p2) + cam.t[1];
+    const float t2 = ((cam.R[6] * p0 + cam.R[7] * p1) + cam.R[8] * p2) + cam.t[2];
+    depth = (cam.K[6] * t0 + cam.K[7] * t1) + cam.K[8] * t2;
+    u = ((cam.K[0] * t0 + cam.K[1] * t1) + cam.K[2] * t2) / depth;
+    v = ((cam.K[3] * t0 + cam.K[4] * t1) + cam.K[5] * t2) / depth;
+}
+PM_DEV bool round_index(float v, int& out) {
+    const float f = v + 0.5f;
+    if (!(f > -1.0f && f < 1.0e8f)) return false;
+    out = (int)f;
+    return true;
+}
+
+constexpr int kMaxFuseNgb = kMaxViews + 1;
+
+__global__ __launch_bounds__(256) void k_fuse(const FuseView* __restrict__ views, int i, const int* __restrict__ src_ids, int num_ngb,
+                                              int use_dynamic, unsigned char* __restrict__ out_valid, float* __restrict__ out9) {
+    const FuseView& R = views[i];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (c >= R.w || r >= R.h) return;
+    const size_t pix = (size_t)r * R.w + c;
+    if (R.mask[pix] == 1) return;
+    const float ref_depth = R.depth[pix];
+    if (ref_depth <= 0.0f) return;
+    const float n0 = R.normal[pix * 3], n1 = R.normal[pix * 3 + 1], n2 = R.normal[pix * 3 + 2];
+    float X0, X1, X2;
+    point_on_world(R.cam, c, r, ref_depth, X0, X1, X2);
+    float sp0 = X0, sp1 = X1, sp2 = X2, sn0 = n0, sn1 = n1, sn2 = n2;
+    float scol = R.gray[pix];
+    int num = 0;
+    float dyn = 0.0f;
+    int used[kMaxFuseNgb];
+    for (int j = 0; j < num_ngb; ++j) used[j] = -1;
+    for (int j = 1; j < num_ngb; ++j) {
+        if (j == num_ngb - 1 && num == 0) break;  // ref :402-403
+        const int s = src_ids[j];
+        const FuseView& S = views[s];
+        float u, v, pd;
+        project_depth(S.cam, X0, X1, X2, u, v, pd);
+        int sr, sc;
+        if (!round_index(v, sr) || !round_index(u, sc)) continue;
+        if (!(sc >= 0 && sc < S.w && sr >= 0 && sr < S.h)) continue;
+        const size_t sidx = (size_t)sr * S.w + sc;
+        if (S.mask[sidx] == 1) continue;
+        const float sd = S.depth[sidx];
+        if (sd <= 0.0f) continue;
+        const float m0 = S.normal[sidx * 3], m1 = S.normal[sidx * 3 + 1], m2 = S.normal[sidx * 3 + 2];
+        float T0, T1, T2;
+        point_on_world(S.cam, sc, sr, sd, T0, T1, T2);
+        float bu, bv, bd;
+        project_depth(R.cam, T0, T1, T2, bu, bv, bd);
+        const float dc = (float)c - bu, dr = (float)r - bv;
+        const float err = __builtin_sqrtf(dc * dc + dr * dr);
+        if (!(err < 2.0f)) continue;
+        const float rel = __builtin_fabsf(bd - ref_depth) / ref_depth;
+        if (!(rel < 0.01f)) continue;
+        const float dot = (n0 * m0 + n1 * m1) + n2 * m2;
+        float angle = d_acos(dot);
+        if (angle != angle) angle = 0.0f;  // ref :233-242
+        if (angle < 0.174533f) {
+            used[j] = (int)sidx;
+            sp0 += T0;
+            sp1 += T1;
+            sp2 += T2;
+            sn0 += m0;
+            sn1 += m1;
+            sn2 += m2;
+            scol += S.gray[sidx];
+            const float idx = (err + 200.0f * rel) + angle * 10.0f;
+            dyn += d_exp(-idx);
+            num++;
+        }
+    }
+    const bool ok = use_dynamic ? (num >= 1 && dyn > 0.3f * (float)num) : (num >= 2);
+    if (!ok) return;
+    const float d = (float)num + 1.0f;
+    float* o = out9 + pix * 9;
+    o[0] = sp0 / d;
+    o[1] = sp1 / d;
+    o[2] = sp2 / d;
+    o[3] = sn0 / d;
+    o[4] = sn1 / d;
+    o[5] = sn2 / d;
+    const float col = scol / d;
+    o[6] = col;
+    o[7] = col;
+    o[8] = col;
+    out_valid[pix] = 1;
+    for (int j = 1; j < num_ngb; ++j)
+        if (used[j] != -1) views[src_ids[j]].mask_next[used[j]] = 1;  // idempotent
+}
+
+}  // namespace pm

@@ -11,6 +11,7 @@
 // name with extension .pgm (binary P5, 8 bit) -- `mogrify -format pgm *.jpg`.
 #include <sys/stat.h>
 
+#include <cfloat>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -202,6 +203,33 @@ void ProcessProblem(const std::string& input_folder, const std::string& output_f
 }
 
 // ---------------------------------------------------------------------------
+// binary PLY of fused points (reference src/PatchMatch.cpp:145-198): x y z nx ny nz as
+// float32, then red green blue as uchar; the colour triple is stored blue-first in
+// PointList::color (OpenCV BGR) and written red-first; non-finite coordinates become 0
+// ---------------------------------------------------------------------------
+void StoreColorPlyFileBinaryPointCloud(const std::string& plyFilePath, const std::vector<PointList>& pc) {
+    std::cout << "store 3D points to ply file" << std::endl;
+    FILE* out = fopen(plyFilePath.c_str(), "wb");
+    if (!out) {
+        std::cout << "Error opening file " << plyFilePath << std::endl;
+        return;
+    }
+    fprintf(out, "ply\nformat binary_little_endian 1.0\nelement vertex %zu\n", pc.size());
+    fprintf(out, "property float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n");
+    fprintf(out, "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n");
+    for (const PointList& p : pc) {
+        float3 X = p.coord;
+        const bool finite = (X.x < FLT_MAX && X.x > -FLT_MAX) && (X.y < FLT_MAX && X.y > -FLT_MAX) && (X.z < FLT_MAX && X.z >= -FLT_MAX);
+        if (!finite) X = float3{0.0f, 0.0f, 0.0f};
+        const char rgb[3] = {(char)(int)p.color.z, (char)(int)p.color.y, (char)(int)p.color.x};
+        fwrite(&X, sizeof(float), 3, out);
+        fwrite(&p.normal, sizeof(float), 3, out);
+        fwrite(rgb, 1, 3, out);
+    }
+    fclose(out);
+}
+
+// ---------------------------------------------------------------------------
 // C entry points for the tests
 // ---------------------------------------------------------------------------
 extern "C" {
@@ -226,6 +254,18 @@ int mpmvs_host_read_dmb(const char* path, float* data, size_t capacity_floats, i
         }
     }
     return -1;
+}
+// points9: n rows of x y z nx ny nz c0 c1 c2 (colour in PointList order)
+int mpmvs_host_write_ply(const char* path, const float* points9, int n) {
+    std::vector<PointList> pc((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const float* p = points9 + 9 * (size_t)i;
+        pc[i].coord = float3{p[0], p[1], p[2]};
+        pc[i].normal = float3{p[3], p[4], p[5]};
+        pc[i].color = float3{p[6], p[7], p[8]};
+    }
+    StoreColorPlyFileBinaryPointCloud(path, pc);
+    return 0;
 }
 int mpmvs_host_read_camera(const char* path, mpmvs_camera* out) {
     *out = ReadCamera(path);

@@ -16,6 +16,13 @@ int writeNormalDmb(const std::string file_path, const Image& normal);
 Camera ReadCamera(const std::string& cam_path);
 // reference GenerateSampleList(const ConfigParams&, ...): the two config values it uses are passed directly
 void GenerateSampleList(const std::string& input_folder, int maxSourceImageNum, int maxImageSize, std::vector<Scene>& Scenes);
+// reference include/PatchMatch.h:29-33,77
+struct PointList {
+    float3 coord;
+    float3 normal;
+    float3 color;
+};
+void StoreColorPlyFileBinaryPointCloud(const std::string& plyFilePath, const std::vector<PointList>& pc);
 bool readGrayImage(const std::string& path, Image& img);  // binary PGM (P5), 8 bit
 void ProcessProblem(const std::string& input_folder, const std::string& output_folder, std::vector<Scene>& Scenes, const int ID,
                     bool geom_consistency, bool planar_prior, uint64_t seed = 0, int device = 0, int max_scale = 2);

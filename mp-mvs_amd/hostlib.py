@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "host", "libmpmvs_host.so")
 SYMBOLS = ["mpmvs_host_triangulate_vertices", "mpmvs_host_delaunay", "mpmvs_host_build_prior", "mpmvs_host_run_pipeline",
            "mpmvs_host_write_dmb", "mpmvs_host_read_dmb", "mpmvs_host_read_camera", "mpmvs_host_sample_list", "mpmvs_host_read_pgm",
-           "mpmvs_host_run_folder", "mpmvs_host_resize_linear"]
+           "mpmvs_host_run_folder", "mpmvs_host_resize_linear", "mpmvs_host_write_ply"]
 _cache = {}
 
 
@@ -43,6 +43,8 @@ def load():
         lib.mpmvs_host_read_pgm.argtypes = [C.c_char_p, P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.mpmvs_host_run_folder.restype = C.c_int
         lib.mpmvs_host_run_folder.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]
+        lib.mpmvs_host_write_ply.restype = C.c_int
+        lib.mpmvs_host_write_ply.argtypes = [C.c_char_p, P, C.c_int]
         lib.mpmvs_host_resize_linear.restype = C.c_int
         lib.mpmvs_host_resize_linear.argtypes = [P, C.c_int, C.c_int, P, C.c_int, C.c_int]
         _cache["lib"] = lib
@@ -196,3 +198,9 @@ def resize_linear(img, new_w, new_h):
     out = np.empty((new_h, new_w), np.float32)
     load().mpmvs_host_resize_linear(a.ctypes.data, a.shape[1], a.shape[0], out.ctypes.data, new_w, new_h)
     return out
+
+
+def write_ply(path, points9):
+    """binary PLY of fused points (reference src/PatchMatch.cpp:145-198)"""
+    a = np.ascontiguousarray(points9, np.float32).reshape(-1, 9)
+    load().mpmvs_host_write_ply(str(path).encode(), a.ctypes.data, len(a))

@@ -65,3 +65,14 @@ def eval_ncc_literal(handle, params, planes_cam, scale, quantize_fraction=False)
     if rc != 0:
         raise RuntimeError(f"orc_eval_ncc_literal failed ({rc})")
     return out
+
+
+def fuse(cams, estimate, depths, normals, grays, sources, use_dynamic=True, sequential_literal=False):
+    """oracle fusion: mode 0 = the snapshot formulation the GPU implements, mode 1 = the
+    reference's literal sequential order (measurement only)"""
+    fusion = importlib.import_module("mp-mvs_amd.fusion")
+    l, _ = lib()
+    fn = l.orc_fuse
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int] + fusion.FUSE_ARGTYPES_TAIL
+    return fusion.call_fuse(fn, (1 if sequential_literal else 0,), cams, estimate, depths, normals, grays, sources, use_dynamic)

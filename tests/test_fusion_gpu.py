@@ -1,0 +1,49 @@
+"""Fusion on the MI355X (mpmvs_fuse) against the oracle's snapshot formulation: bit exact."""
+import importlib
+
+import numpy as np
+import pytest
+
+from test_fusion_cpu import _scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("use_dynamic", [True, False])
+def test_fusion_bit_exact(pm, oracle, engine, use_dynamic):
+    fusion = importlib.import_module("mp-mvs_amd.fusion")
+    sc, cams, depths, normals, grays, neigh = _scene(pm, size=(128, 96))
+    depths[2][10:30, 20:60] = 0.0
+    est = [True, True, False, True, True, True]
+    cg, vg, mg = fusion.fuse(cams, est, depths, normals, grays, neigh, use_dynamic)
+    cc, vc, mc = oracle.fuse(cams, est, depths, normals, grays, neigh, use_dynamic)
+    assert len(cg) == len(cc) and len(cg) > 1000
+    assert np.array_equal(cg, cc)
+    for a, b in zip(vg, vc):
+        assert np.array_equal(a, b)
+    for a, b in zip(mg, mc):
+        assert np.array_equal(a, b)
+
+
+def test_fusion_of_estimated_maps(pm, oracle, engine):
+    """end of the pipeline: depth/normal maps estimated by the HIP path (photometric pass per
+    image) fused on the GPU == the same maps fused by the oracle; points lie on the surface"""
+    fusion = importlib.import_module("mp-mvs_amd.fusion")
+    sc, neigh = pm.synth.make_grid_scene(128, 96, 3, 2, spacing=0.4, rot_deg=1.0, quantize=True)
+    cams = [v.cam for v in sc.views]
+    imgs = [v.image for v in sc.views]
+    depths, normals = [], []
+    for i in range(6):
+        h = engine.create(0)
+        ids = [i] + neigh[i]
+        h.set_views([cams[j] for j in ids], [imgs[j] for j in ids])
+        dmin, dmax = pm.synth.kernel_depth_range(cams[i])
+        h.run(pm.PatchMatchParams(num_images=len(ids), depth_min=float(dmin), depth_max=float(dmax), max_scale=1), 100 + i)
+        planes, _ = h.get()
+        depths.append(planes[..., 3].copy())
+        normals.append(planes[..., :3].copy())
+    cg, vg, mg = fusion.fuse(cams, [True] * 6, depths, normals, imgs, neigh)
+    cc, vc, mc = oracle.fuse(cams, [True] * 6, depths, normals, imgs, neigh)
+    assert np.array_equal(cg, cc) and all(np.array_equal(a, b) for a, b in zip(mg, mc))
+    err = np.abs(cg[:, 2] - pm.synth.height_field(cg[:, 0].astype(np.float64), cg[:, 1].astype(np.float64)))
+    assert len(cg) > 5000 and np.median(err) < 0.02

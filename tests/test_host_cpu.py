@@ -206,3 +206,14 @@ def test_resize_linear_geometry(hostlib):
     half = hostlib.resize_linear(img, 20, 15)
     assert np.allclose(half, img.reshape(15, 2, 20, 2).mean((1, 3)), atol=1e-3)
     assert np.array_equal(hostlib.resize_linear(img, 40, 30), img)
+
+
+def test_ply_layout(hostlib, tmp_path):
+    pts = np.array([[1, 2, 3, 0, 0, -1, 10, 20, 30], [np.inf, 0, 0, 0, 1, 0, 255, 128, 0]], np.float32)
+    hostlib.write_ply(tmp_path / "m.ply", pts)
+    raw = open(tmp_path / "m.ply", "rb").read()
+    head, body = raw.split(b"end_header\n")
+    assert b"format binary_little_endian 1.0" in head and b"element vertex 2" in head
+    assert len(body) == 2 * 27
+    assert np.frombuffer(body[:24], np.float32).tolist() == [1, 2, 3, 0, 0, -1] and list(body[24:27]) == [30, 20, 10]   # red green blue
+    assert np.frombuffer(body[27:39], np.float32).tolist() == [0, 0, 0]                                               # non-finite -> origin
