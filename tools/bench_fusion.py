@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""fusion throughput on one GPU: 8 images of 1600x1200 (ground-truth maps + noise), GPU vs oracle"""
+import importlib, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa
+pm = importlib.import_module("mp-mvs_amd")
+fusion = importlib.import_module("mp-mvs_amd.fusion")
+from test_fusion_cpu import _scene
+from oracle import binding as ob
+sc, cams, depths, normals, grays, neigh = _scene(pm, n_grid=(4, 2), size=(1600, 1200))
+fusion.fuse(cams, [True] * 8, depths, normals, grays, neigh)  # warm-up (library load)
+t0 = time.perf_counter(); cg, vg, mg = fusion.fuse(cams, [True] * 8, depths, normals, grays, neigh); tg = time.perf_counter() - t0
+ob.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+t0 = time.perf_counter(); cc, vc, mc = ob.fuse(cams, [True] * 8, depths, normals, grays, neigh); tc = time.perf_counter() - t0
+t0 = time.perf_counter(); cs, vs, ms = ob.fuse(cams, [True] * 8, depths, normals, grays, neigh, sequential_literal=True); ts = time.perf_counter() - t0
+print(json.dumps({"images": 8, "size": [1600, 1200], "points": int(len(cg)), "gpu_incl_transfers_s": round(tg, 3), "oracle_snapshot_16thr_s": round(tc, 3),
+                  "oracle_sequential_literal_s": round(ts, 3), "bit_exact": bool(np.array_equal(cg, cc)), "points_sequential": int(len(cs)),
+                  "Mpix_per_s_gpu": round(8 * 1600 * 1200 / tg / 1e6, 1)}))
