@@ -164,6 +164,9 @@ int mpmvs_fuse(int device, int n, const mpmvs_camera* cams, const int* estimate,
                int use_dynamic_consistency, unsigned char* const* out_valid, float* const* out_points9,
                unsigned char* const* out_masks);
 
+/* device time (ms, HIP events) of the kernels of the last mpmvs_fuse call */
+float mpmvs_fuse_kernel_ms(void);
+
 /* ---- resident texture format ---------------------------------------------- */
 /* Source images whose pixels are all integers in [0, 255] (the reference's
  * imread(GRAYSCALE) -> convertTo(CV_32F) path, src/PatchMatch.cpp:877-882) are

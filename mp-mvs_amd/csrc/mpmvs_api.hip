@@ -687,6 +687,10 @@ int mpmvs_rng(uint64_t seed, uint32_t pix, uint32_t launch_id, int n, void* out)
     return rc;
 }
 
+static float g_fuse_kernel_ms = 0.0f;
+// device time of the kernels (and mask copies) of the last mpmvs_fuse call, HIP events
+float mpmvs_fuse_kernel_ms(void) { return g_fuse_kernel_ms; }
+
 // depth-map fusion, snapshot formulation (pm_fusion.hpp); host buffers in and out
 int mpmvs_fuse(int device, int n, const mpmvs_camera* cams, const int* estimate, const float* const* depths, const float* const* normals,
                const float* const* gray, const int* src_off, const int* src_ids, int use_dynamic, unsigned char* const* out_valid,
@@ -737,6 +741,10 @@ int mpmvs_fuse(int device, int n, const mpmvs_camera* cams, const int* estimate,
             hipMemcpy(d_src, src_ids, sizeof(int) * src_off[n], hipMemcpyHostToDevice) != hipSuccess)
             rc = -100;
     }
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    (void)hipEventCreate(&ev0);
+    (void)hipEventCreate(&ev1);
+    (void)hipEventRecord(ev0, nullptr);
     for (int i = 0; i < n && !rc; ++i) {
         if (!estimate[i]) continue;
         const int b = src_off[i], num_ngb = src_off[i + 1] - b;
@@ -750,7 +758,11 @@ int mpmvs_fuse(int device, int n, const mpmvs_camera* cams, const int* estimate,
             if (hipMemcpyAsync(d_mask[s], d_next[s], (size_t)hv[s].w * hv[s].h, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) rc = -100;
         }
     }
+    (void)hipEventRecord(ev1, nullptr);
     if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -100;
+    if (!rc) (void)hipEventElapsedTime(&g_fuse_kernel_ms, ev0, ev1);
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
     for (int i = 0; i < n && !rc; ++i) {
         const size_t wh = (size_t)hv[i].w * hv[i].h;
         if (hipMemcpy(out_valid[i], d_valid[i], wh, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(out_points9[i], d_out[i], wh * 36, hipMemcpyDeviceToHost) != hipSuccess ||

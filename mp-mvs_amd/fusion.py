@@ -49,3 +49,10 @@ def fuse(cams, estimate, depths, normals, grays, sources, use_dynamic=True, devi
     fn.restype = C.c_int
     fn.argtypes = [C.c_int] + FUSE_ARGTYPES_TAIL
     return call_fuse(fn, (int(device),), cams, estimate, depths, normals, grays, sources, use_dynamic)
+
+
+def last_kernel_ms():
+    from . import engine
+    lib, _ = engine.load()
+    lib.mpmvs_fuse_kernel_ms.restype = C.c_float
+    return float(lib.mpmvs_fuse_kernel_ms())
