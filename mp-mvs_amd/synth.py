@@ -116,7 +116,7 @@ def make_scene(width, height, centers, seed=SCENE_SEED, rot_deg=2.0, depth_min=3
 _RING = [(1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (-1, -1), (1, -1), (-1, 1)]
 
 
-def make_problem_scene(width, height, n_src=8, spacing=0.15, **kw):
+def make_problem_scene(width, height, n_src=8, spacing=0.15, **kw):  # kw: seed, rot_deg, depth_min, depth_max, quantize
     """One Problem: reference at the origin + n_src (<= 8) neighbours of the 3x3 grid."""
     assert 1 <= n_src <= 8
     centers = [(0.0, 0.0, 0.0)] + [(spacing * dx, spacing * dy, 0.0) for dx, dy in _RING[:n_src]]

@@ -1,0 +1,67 @@
+"""Seeded randomized parity sweep: random sizes / view counts / scales / iterations /
+texture formats / modes, whole Run() schedules on the HIP path against the oracle, bit exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_random_configuration_bit_exact(pm, oracle, engine, case):
+    rng = np.random.default_rng(1000 + case)
+    W = int(rng.integers(6, 90))
+    H = int(rng.integers(6, 70))
+    V = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12]))
+    quantize = bool(rng.integers(0, 2))
+    max_scale = int(rng.integers(0, 3))
+    iters = int(rng.integers(1, 4))
+    spacing = float(rng.uniform(0.2, 0.8))
+    sc = pm.synth.make_problem_scene(W, H, n_src=min(V, 8), spacing=spacing, rot_deg=float(rng.uniform(0, 4)), quantize=quantize,
+                                     seed=int(rng.integers(1, 10 ** 6)))
+    ids = [1 + (i % 8) for i in range(V)]
+    cams, imgs = sc.problem(0, ids)
+    imgs = [im.copy() for im in imgs]
+    if rng.integers(0, 3) == 0:            # a textureless patch (variance sentinel)
+        imgs[0][: H // 2, : W // 3] = 128.0
+    dmin, dmax = pm.synth.kernel_depth_range(cams[0])
+    if rng.integers(0, 4) == 0:            # a depth range that throws hypotheses out of view
+        dmin = dmin * 0.2
+    p = pm.PatchMatchParams(num_images=V + 1, depth_min=float(dmin), depth_max=float(dmax), max_scale=max_scale, max_iterations=iters,
+                            top_k=int(rng.integers(1, 6)), sigma_spatial=float(rng.uniform(2, 8)), sigma_color=float(rng.uniform(1, 6)))
+    gpu, cpu = engine.create(0), oracle.create()
+    for h in (gpu, cpu):
+        h.set_views(cams, imgs)
+        h.run(p, 77 + case)
+    gp, gc = gpu.get()
+    cp, cc = cpu.get()
+    assert _same(gp, cp) and _same(gc, cc) and np.array_equal(gpu.get_selected_views(), cpu.get_selected_views()), f"photometric W={W} H={H} V={V}"
+    mode = int(rng.integers(0, 3))
+    if mode >= 1:                          # geometric consistency on top
+        depths = []
+        for i in ids:
+            d = sc.views[i].gt_depth * (1.0 + 0.01 * rng.standard_normal((H, W))).astype(np.float32)
+            d[rng.uniform(size=d.shape) < 0.05] = 0.0
+            depths.append(d)
+        p.geom_consistency, p.max_iterations = True, int(rng.integers(1, 3))
+        for h in (gpu, cpu):
+            h.set_src_depths(depths)
+            h.run(p, 78 + case)
+        g3, c3 = gpu.get(geom=True), cpu.get(geom=True)
+        assert all(_same(a, b) for a, b in zip(g3, c3)), f"geom W={W} H={H} V={V}"
+    if mode == 2:                          # planar prior on top
+        prior = np.zeros((H, W, 4), np.float32)
+        n = rng.normal(size=(H, W, 3)) * 0.1
+        n[..., 2] = -1.0
+        n /= np.linalg.norm(n, axis=-1, keepdims=True)
+        prior[..., :3] = n
+        prior[..., 3] = rng.uniform(dmin, dmax, (H, W))
+        mask = (rng.uniform(size=(H, W)) < 0.5).astype(np.uint32) * 7
+        p.geom_consistency, p.planar_prior, p.max_iterations = False, True, int(rng.integers(1, 4))
+        for h in (gpu, cpu):
+            h.set_prior(prior, mask)
+            h.run(p, 79 + case)
+        assert _same(gpu.get()[0], cpu.get()[0]) and _same(gpu.get()[1], cpu.get()[1]), f"prior W={W} H={H} V={V}"
