@@ -541,13 +541,12 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int s
         }
     };
     // phase 2: interpolate; even/odd taps accumulate in the two halves of packed registers
-    auto consume_column = [&](int a, const BilinearTap<U8>(&tap)[6]) {
+    auto consume_column = [&](const float4 (&wq)[3], const BilinearTap<U8>(&tap)[6]) {
         f32x2 A1 = {0.0f, 0.0f}, A2 = {0.0f, 0.0f}, A3 = {0.0f, 0.0f};
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const f32x2 sv = {tap[2 * j].value(), tap[2 * j + 1].value()};
-            const float4 wq = rw.lw[(a * 3 + j) * kBlockThreads];
-            const f32x2 w2 = {wq.x, wq.y}, wr2 = {wq.z, wq.w};
+            const f32x2 w2 = {wq[j].x, wq[j].y}, wr2 = {wq[j].z, wq[j].w};
             const f32x2 ws = w2 * sv;
             A1 = __builtin_elementwise_fma(w2, sv, A1);
             A2 = __builtin_elementwise_fma(ws, sv, A2);
@@ -582,35 +581,45 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int s
             tap[2 * j + 1].issue(tex, X[2 * j + 1] * i1, Y[2 * j + 1] * i1);
         }
     };
-    auto consume_column = [&](int a, const BilinearTap<U8>(&tap)[6]) {
+    auto consume_column = [&](const float4 (&wq)[3], const BilinearTap<U8>(&tap)[6]) {
         float E1 = 0.0f, E2 = 0.0f, E3 = 0.0f, O1 = 0.0f, O2 = 0.0f, O3 = 0.0f;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const float se = tap[2 * j].value(), so = tap[2 * j + 1].value();
-            const float4 wq = rw.lw[(a * 3 + j) * kBlockThreads];
-            const float wse = wq.x * se, wso = wq.y * so;
-            E1 = __builtin_fmaf(wq.x, se, E1);
-            O1 = __builtin_fmaf(wq.y, so, O1);
+            const float wse = wq[j].x * se, wso = wq[j].y * so;
+            E1 = __builtin_fmaf(wq[j].x, se, E1);
+            O1 = __builtin_fmaf(wq[j].y, so, O1);
             E2 = __builtin_fmaf(wse, se, E2);
             O2 = __builtin_fmaf(wso, so, O2);
-            E3 = __builtin_fmaf(wq.z, se, E3);
-            O3 = __builtin_fmaf(wq.w, so, O3);
+            E3 = __builtin_fmaf(wq[j].z, se, E3);
+            O3 = __builtin_fmaf(wq[j].w, so, O3);
         }
         T1 += E1 + O1;
         T2 += E2 + O2;
         T3 += E3 + O3;
     };
 #endif
-    // software pipeline over the 6 columns: the gathers of column a+1 are in
-    // flight while column a is interpolated, so a wave never drains its loads
+    // software pipeline over the 6 columns: the gathers of column a+1 are in flight
+    // while column a is interpolated, so a wave never drains its loads; the LDS
+    // weight records of a column are fetched one column ahead for the same reason
+    auto load_weights = [&](int a, float4(&wq)[3]) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) wq[j] = rw.lw[(a * 3 + j) * kBlockThreads];
+    };
     BilinearTap<U8> tapA[6], tapB[6];
+    float4 wA[3], wB[3];
+    load_weights(0, wA);
     issue_column(0, tapA);
 #pragma unroll
     for (int a = 0; a < 6; a += 2) {
         issue_column(a + 1, tapB);
-        consume_column(a, tapA);
-        if (a + 2 < 6) issue_column(a + 2, tapA);
-        consume_column(a + 1, tapB);
+        load_weights(a + 1, wB);
+        consume_column(wA, tapA);
+        if (a + 2 < 6) {
+            issue_column(a + 2, tapA);
+            load_weights(a + 2, wA);
+        }
+        consume_column(wB, tapB);
     }
     const float ms = T1 * rw.inv_w, mss = T2 * rw.inv_w, mrs = T3 * rw.inv_w;
     const float var_s = __builtin_fmaf(-ms, ms, mss);
