@@ -88,7 +88,7 @@ def render_view(width, height, K, R, Cc, seed, fs):
     return img.astype(np.float32), d.astype(np.float32)
 
 
-def make_scene(width, height, centers, seed=SCENE_SEED, rot_deg=2.0, depth_min=3.0, depth_max=8.0, quantize=False):
+def make_scene(width, height, centers, seed=SCENE_SEED, rot_deg=2.0, depth_min=3.0, depth_max=8.0, quantize=False, focal_jitter=0.0):
     """Cameras at `centers` (N x 3 world positions), fx = fy = 0.9 W, principal
     point at the image centre; camera 0..N-1 in the order given.  quantize=True
     rounds the images to integers 0..255 like an 8-bit camera image (what the
@@ -100,7 +100,14 @@ def make_scene(width, height, centers, seed=SCENE_SEED, rot_deg=2.0, depth_min=3
     for Cc in np.asarray(centers, np.float64):
         R = _small_rotation(rng, rot_deg)
         t = -R @ Cc
-        cam = make_camera(K, R, t, height, width, depth_min, depth_max)
+        Kv = K.copy()
+        if focal_jitter > 0:   # per-view intrinsics: different focal lengths and principal points
+            f = rng.uniform(1.0 - focal_jitter, 1.0 + focal_jitter, 2)
+            Kv[0, 0] *= f[0]
+            Kv[1, 1] *= f[1]
+            Kv[0, 2] += rng.uniform(-0.05, 0.05) * width
+            Kv[1, 2] += rng.uniform(-0.05, 0.05) * height
+        cam = make_camera(Kv, R, t, height, width, depth_min, depth_max)
         # render with the fp32-rounded camera so images and Camera agree
         Kf = np.array(cam.K, np.float64).reshape(3, 3)
         Rf = np.array(cam.R, np.float64).reshape(3, 3)

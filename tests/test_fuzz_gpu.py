@@ -20,8 +20,9 @@ def test_random_configuration_bit_exact(pm, oracle, engine, case):
     max_scale = int(rng.integers(0, 3))
     iters = int(rng.integers(1, 4))
     spacing = float(rng.uniform(0.2, 0.8))
-    sc = pm.synth.make_problem_scene(W, H, n_src=min(V, 8), spacing=spacing, rot_deg=float(rng.uniform(0, 4)), quantize=quantize,
-                                     seed=int(rng.integers(1, 10 ** 6)))
+    harsh = case % 3 == 0   # every third case: strongly different cameras
+    sc = pm.synth.make_problem_scene(W, H, n_src=min(V, 8), spacing=spacing, rot_deg=float(rng.uniform(0, 15 if harsh else 4)), quantize=quantize,
+                                     seed=int(rng.integers(1, 10 ** 6)), focal_jitter=0.25 if harsh else 0.0)
     ids = [1 + (i % 8) for i in range(V)]
     cams, imgs = sc.problem(0, ids)
     imgs = [im.copy() for im in imgs]
