@@ -140,3 +140,21 @@ def test_folder_pipeline_matches_oracle(pm, oracle, engine, tmp_path):
         assert np.array_equal(hostlib.read_dmb(d / "depths.dmb"), state[i][0][..., 3]), f"depths of image {i}"
         assert np.array_equal(hostlib.read_dmb(d / "normals.dmb"), state[i][0][..., :3]), f"normals of image {i}"
         assert np.array_equal(hostlib.read_dmb(d / "costs.dmb"), state[i][1]), f"costs of image {i}"
+
+
+def test_end_to_end_scene_tool(pm, engine, tmp_path):
+    """tools/run_scene.py: schedule -> fusion -> PLY on a small scene"""
+    import json
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ply = tmp_path / "scene.ply"
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "run_scene.py"), "--size", "160x120", "--grid", "3x2", "--out", str(ply)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rep["images"] == 6 and rep["fused_points"] > 2000 and rep["median_point_error"] < 0.05
+    assert rep["depth_within_1pct_of_gt"] > 0.7
+    raw = open(ply, "rb").read()
+    assert raw.startswith(b"ply\n") and len(raw.split(b"end_header\n", 1)[1]) == rep["fused_points"] * 27
