@@ -230,6 +230,80 @@ void StoreColorPlyFileBinaryPointCloud(const std::string& plyFilePath, const std
 }
 
 // ---------------------------------------------------------------------------
+// RunFusion over a dataset folder (reference src/PatchMatch.cpp:287-504): reads every
+// estimated image's depths.dmb / normals.dmb, camera and image, fuses them on the GPU
+// (mpmvs_fuse, the snapshot formulation of DESIGN.md section 8) and writes
+// <output>/MPMVS_model.ply.  Colour = the grey value (this build reads grey PGM images).
+// Returns the number of points, or -1.
+// ---------------------------------------------------------------------------
+long RunFusion(const std::string& input_folder, const std::string& output_folder, std::vector<Scene>& Scenes, bool use_dynamic_consistency, int device) {
+    const int n = (int)Scenes.size();
+    std::vector<Camera> cams(n);
+    std::vector<int> estimate(n, 0), src_off(1, 0), src_ids;
+    std::vector<Image> depths(n), normals(n), grays(n);
+    for (int i = 0; i < n; ++i) {
+        Scene& s = Scenes[i];
+        if (s.estimate) {
+            std::cout << "Reading image " << id8(i) << "..." << std::endl;
+            const std::string res = input_folder + "/MPMVS/2333_" + id8(s.refID);
+            if (!readDepthDmb(res + "/depths.dmb", depths[i]) || !readNormalDmb(res + "/normals.dmb", normals[i])) return -1;
+            if (s.image.empty() && !readGrayImage(input_folder + "/images/" + id8(s.refID) + ".pgm", s.image)) return -1;
+            cams[i] = ReadCamera(input_folder + "/cams/" + id8(s.refID) + "_cam.txt");
+            grays[i] = s.image;
+            if (grays[i].rows != depths[i].rows || grays[i].cols != depths[i].cols) {  // RescaleImageAndCamera, reference :262-284
+                const float sx = depths[i].cols / (float)grays[i].cols, sy = depths[i].rows / (float)grays[i].rows;
+                grays[i] = ResizeLinear(grays[i], depths[i].cols, depths[i].rows);
+                cams[i].K[0] *= sx;
+                cams[i].K[2] *= sx;
+                cams[i].K[4] *= sy;
+                cams[i].K[5] *= sy;
+            }
+            cams[i].width = depths[i].cols;
+            cams[i].height = depths[i].rows;
+            estimate[i] = 1;
+            for (int id : s.srcID) src_ids.push_back(id);
+        } else {  // placeholder image (reference :314-322): 1x1, never estimated, never a source
+            cams[i] = Camera{};
+            cams[i].width = cams[i].height = 1;
+            depths[i] = Image(1, 1, 1);
+            normals[i] = Image(1, 1, 3);
+            grays[i] = Image(1, 1, 1);
+            src_ids.push_back(i);
+        }
+        src_off.push_back((int)src_ids.size());
+    }
+    std::vector<const float*> dp(n), np_(n), gp(n);
+    std::vector<std::vector<unsigned char>> valid(n), masks(n);
+    std::vector<std::vector<float>> pts(n);
+    std::vector<unsigned char*> vp(n), mp(n);
+    std::vector<float*> pp(n);
+    for (int i = 0; i < n; ++i) {
+        const size_t wh = (size_t)cams[i].width * cams[i].height;
+        dp[i] = depths[i].data.data();
+        np_[i] = normals[i].data.data();
+        gp[i] = grays[i].data.data();
+        valid[i].assign(wh, 0);
+        masks[i].assign(wh, 0);
+        pts[i].assign(wh * 9, 0.0f);
+        vp[i] = valid[i].data();
+        mp[i] = masks[i].data();
+        pp[i] = pts[i].data();
+    }
+    if (mpmvs_fuse(device, n, cams.data(), estimate.data(), dp.data(), np_.data(), gp.data(), src_off.data(), src_ids.data(), use_dynamic_consistency ? 1 : 0,
+                   vp.data(), pp.data(), mp.data()) != 0)
+        return -1;
+    std::vector<PointList> cloud;
+    for (int i = 0; i < n; ++i)
+        for (size_t k = 0; k < valid[i].size(); ++k)
+            if (valid[i][k]) {
+                const float* p = &pts[i][k * 9];
+                cloud.push_back(PointList{float3{p[0], p[1], p[2]}, float3{p[3], p[4], p[5]}, float3{p[6], p[7], p[8]}});
+            }
+    StoreColorPlyFileBinaryPointCloud(output_folder + "/MPMVS_model.ply", cloud);
+    return (long)cloud.size();
+}
+
+// ---------------------------------------------------------------------------
 // C entry points for the tests
 // ---------------------------------------------------------------------------
 extern "C" {
@@ -299,6 +373,14 @@ int mpmvs_host_read_pgm(const char* path, float* data, size_t capacity_floats, i
 }
 // the reference's main() pass loops (src/main.cpp:20-41) over a dataset folder, sequentially
 // and in place (Gauss-Seidel through the files, as the reference does)
+// reference main()'s last step (src/main.cpp:49): fuse the maps of a processed folder into
+// <folder>/MPMVS/MPMVS_model.ply; returns the number of points or -1
+long mpmvs_host_fuse_folder(const char* input_folder, int device, int max_src, int use_dynamic_consistency) {
+    std::vector<Scene> Scenes;
+    GenerateSampleList(input_folder, max_src, 3200, Scenes);
+    const std::string in = input_folder;
+    return RunFusion(in, in + "/MPMVS", Scenes, use_dynamic_consistency != 0, device);
+}
 int mpmvs_host_run_folder(const char* input_folder, int device, int max_src, int geom_iterations, int planar_prior,
                           int geomPlanarPrior, int max_scale, uint64_t seed) {
     std::vector<Scene> Scenes;

@@ -23,6 +23,8 @@ struct PointList {
     float3 color;
 };
 void StoreColorPlyFileBinaryPointCloud(const std::string& plyFilePath, const std::vector<PointList>& pc);
+// reference RunFusion(const ConfigParams&, const std::vector<Scene>&) (include/PatchMatch.h:85); returns the point count
+long RunFusion(const std::string& input_folder, const std::string& output_folder, std::vector<Scene>& Scenes, bool use_dynamic_consistency, int device = 0);
 bool readGrayImage(const std::string& path, Image& img);  // binary PGM (P5), 8 bit
 void ProcessProblem(const std::string& input_folder, const std::string& output_folder, std::vector<Scene>& Scenes, const int ID,
                     bool geom_consistency, bool planar_prior, uint64_t seed = 0, int device = 0, int max_scale = 2);

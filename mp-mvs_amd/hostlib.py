@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "host", "libmpmvs_host.so")
 SYMBOLS = ["mpmvs_host_triangulate_vertices", "mpmvs_host_delaunay", "mpmvs_host_build_prior", "mpmvs_host_run_pipeline",
            "mpmvs_host_write_dmb", "mpmvs_host_read_dmb", "mpmvs_host_read_camera", "mpmvs_host_sample_list", "mpmvs_host_read_pgm",
-           "mpmvs_host_run_folder", "mpmvs_host_resize_linear", "mpmvs_host_write_ply"]
+           "mpmvs_host_run_folder", "mpmvs_host_resize_linear", "mpmvs_host_write_ply", "mpmvs_host_fuse_folder"]
 _cache = {}
 
 
@@ -43,6 +43,8 @@ def load():
         lib.mpmvs_host_read_pgm.argtypes = [C.c_char_p, P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.mpmvs_host_run_folder.restype = C.c_int
         lib.mpmvs_host_run_folder.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]
+        lib.mpmvs_host_fuse_folder.restype = C.c_long
+        lib.mpmvs_host_fuse_folder.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
         lib.mpmvs_host_write_ply.restype = C.c_int
         lib.mpmvs_host_write_ply.argtypes = [C.c_char_p, P, C.c_int]
         lib.mpmvs_host_resize_linear.restype = C.c_int
@@ -204,3 +206,11 @@ def write_ply(path, points9):
     """binary PLY of fused points (reference src/PatchMatch.cpp:145-198)"""
     a = np.ascontiguousarray(points9, np.float32).reshape(-1, 9)
     load().mpmvs_host_write_ply(str(path).encode(), a.ctypes.data, len(a))
+
+
+def fuse_folder(folder, device=0, max_src=20, use_dynamic=True):
+    """RunFusion over a processed dataset folder -> <folder>/MPMVS/MPMVS_model.ply; returns the point count"""
+    n = load().mpmvs_host_fuse_folder(str(folder).encode(), device, max_src, 1 if use_dynamic else 0)
+    if n < 0:
+        raise RuntimeError("fuse_folder failed")
+    return int(n)

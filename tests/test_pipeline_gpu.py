@@ -140,6 +140,14 @@ def test_folder_pipeline_matches_oracle(pm, oracle, engine, tmp_path):
         assert np.array_equal(hostlib.read_dmb(d / "depths.dmb"), state[i][0][..., 3]), f"depths of image {i}"
         assert np.array_equal(hostlib.read_dmb(d / "normals.dmb"), state[i][0][..., :3]), f"normals of image {i}"
         assert np.array_equal(hostlib.read_dmb(d / "costs.dmb"), state[i][1]), f"costs of image {i}"
+    # reference main()'s last step: RunFusion over the written maps -> MPMVS_model.ply
+    npts = hostlib.fuse_folder(tmp_path)
+    fusion = importlib.import_module("mp-mvs_amd.fusion")
+    cloud, _, _ = oracle.fuse(cams, [True] * 6, [state[i][0][..., 3] for i in range(6)], [np.ascontiguousarray(state[i][0][..., :3]) for i in range(6)], imgs, neigh)
+    assert npts == len(cloud) and npts > 100
+    body = open(tmp_path / "MPMVS" / "MPMVS_model.ply", "rb").read().split(b"end_header\n", 1)[1]
+    xyz = np.frombuffer(body, np.uint8).reshape(npts, 27)[:, :12].copy().view(np.float32)
+    assert np.array_equal(xyz, cloud[:, :3])
 
 
 def test_end_to_end_scene_tool(pm, engine, tmp_path):
