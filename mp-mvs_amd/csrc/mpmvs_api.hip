@@ -4,7 +4,7 @@
 //
 // HBM layout per context:
 //   reference image   (W+40) x (H+40) fp32, replicated apron 20  (window radius <= 20)
-//   source images     fp32 format: (w+1) x (h+1) fp32, last row/column replicated
+//   source images     fp32 format: w x h float4, each packing the 2x2 bilinear footprint of one texel
 //                     u8 format (all images 8-bit exact): w x h dwords, each packing the 2x2
 //                     bilinear footprint of one texel (pm_device.hpp SrcTex8)
 //   source depth maps dense w x h fp32 (geometric consistency only)
@@ -171,14 +171,14 @@ static int upload_padded(mpmvs_ctx* c, const float* host, size_t pitch, int w, i
     return 0;
 }
 
-// host image -> dense staging buffer -> (w+1) x (h+1) fp32 texture (last row/column replicated)
+// host image -> dense staging buffer -> quad-packed fp32 texture (w x h float4)
 static int upload_extended(mpmvs_ctx* c, const float* host, size_t pitch, int w, int h, float** out) {
     float* d_raw = nullptr;
     HIPCHK(c, hipMalloc(&d_raw, (size_t)w * h * 4));
     HIPCHK(c, hipMemcpy2DAsync(d_raw, (size_t)w * 4, host, pitch, (size_t)w * 4, h, hipMemcpyHostToDevice, c->stream));
     float* d_e = nullptr;
-    HIPCHK(c, hipMalloc(&d_e, (size_t)(w + 1) * (h + 1) * 4));
-    hipLaunchKernelGGL(k_extend, dim3((w + 1 + 255) / 256, h + 1), dim3(256), 0, c->stream, d_raw, w, h, d_e);
+    HIPCHK(c, hipMalloc(&d_e, (size_t)w * h * 16));
+    hipLaunchKernelGGL(k_pack_quads_f32, dim3((w + 255) / 256, h), dim3(256), 0, c->stream, d_raw, w, h, (float4*)d_e);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipFree(d_raw));
@@ -299,7 +299,7 @@ int mpmvs_set_views(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* 
             o.img8 = c->d_src8[v - 1];
         } else {
             if ((rc = upload_extended(c, images[v], pitch, w, h, &c->d_src[v - 1]))) return rc;
-            o.pitch = w + 1;
+            o.pitch = w;
             o.img = c->d_src[v - 1];
         }
     }

@@ -35,8 +35,8 @@ struct ViewDev {
     float b[3];        // K_s t_rel
     float wf, hf;      // (float)width, (float)height
     float wm1, hm1;    // (float)(width-1), (float)(height-1)
-    const float* img;  // fp32 format: (w+1) x (h+1) image, last row/column replicated
-    int pitch;         // floats per row (= w + 1)
+    const float* img;  // fp32 format: w x h float4 quad texels (see SrcTex) or null
+    int pitch;         // texels per row (= w)
     const uint32_t* img8;  // quad-packed u8 texture (see SrcTex8) or null
     int pitch8;            // dwords per row of the quad-packed texture (= w)
     int w, h;
@@ -369,36 +369,33 @@ PM_DEV int texel_offset(int iy, int ix, int pitch) {
     return (int)((__umul24((unsigned)iy, (unsigned)pitch) + (unsigned)ix) << 2);
 }
 
-// Per-view source image handle: a 128-bit buffer resource (wave-uniform, built
-// from scalar loads) so the taps are buffer_load_dwordx2 with a 32-bit byte
-// offset instead of flat loads with 64-bit address arithmetic; out-of-range
-// offsets (impossible by construction: the coordinate is clamped first) would
-// read 0 instead of faulting.
+// Per-view source image handle, fp32 format: w x h float4 texels, texel (x, y) packing
+// its whole bilinear footprint (P[y][x], P[y][x+1], P[y+1][x], P[y+1][x+1]) (indices
+// clamped), so ONE buffer_load_dwordx4 serves a tap.  The 128-bit buffer resource is
+// wave-uniform (built from scalar loads); the 32-bit byte offset is range checked by the
+// hardware (an out-of-range offset -- impossible, the coordinate is clamped first --
+// would read 0 instead of faulting).  Measured on cfg 1 with non-integer images:
+// 4.70 ms per update launch against 5.41 ms for a plain (w+1) x (h+1) image read with two
+// 8-byte loads per tap (the texture-address path, not the cache footprint, is the limit
+// once the gathers are pipelined; before that the two-load form was faster).
 struct SrcTex {
     __amdgpu_buffer_rsrc_t rsrc;
-    int pitch;      // floats per padded row
-    int row_bytes;  // pitch * 4
+    int pitch;  // texels per row (= w)
     float wm1, hm1;
 };
 
 PM_DEV SrcTex make_src_tex(const ViewDev& vw) {
     SrcTex t;
     t.pitch = vw.pitch;
-    t.row_bytes = vw.pitch * 4;
     t.wm1 = vw.wm1;
     t.hm1 = vw.hm1;
-    const int bytes = vw.pitch * (vw.h + 1) * 4;
+    const int bytes = vw.pitch * vw.h * 16;
     t.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vw.img), (short)0, bytes, 0x00020000);
     return t;
 }
 
 // Software bilinear fetch with clamp addressing (CUDA tex2D(t, x+0.5, y+0.5), linear
-// filter; ref .cu:377, SURVEY a-2): see BilinearTap below.  The resident image has
-// one replicated extra row and column (w+1 x h+1), so with the coordinate clamped
-// to [0, w-1] x [0, h-1] the four texels of a tap are always in-bounds; two 8-byte
-// loads fetch them.  (A row-pair interleaved fp32 layout with ONE 16-byte load per tap was
-// measured slower: its doubled cache footprint costs more than the halved
-// instruction count saves.)
+// filter; ref .cu:377, SURVEY a-2): see BilinearTap below.
 
 // Quad-packed 8-bit texture, used when every pixel of every source image is an
 // integer in [0, 255] (always true for the reference's input unless it rescales:
@@ -430,26 +427,25 @@ PM_DEV SrcTex8 make_src_tex8(const ViewDev& vw) {
 template <bool U8>
 struct BilinearTap;
 
+typedef float f32x4q __attribute__((ext_vector_type(4)));
 template <>
 struct BilinearTap<false> {
     float ax, ay;
-    f32x2 r0, r1;
+    f32x4q q;  // (P[y][x], P[y][x+1], P[y+1][x], P[y+1][x+1])
     PM_DEV void issue(const SrcTex& t, float sx, float sy) {
         const float cx = clamp_coord(sx, t.wm1);
         const float cy = clamp_coord(sy, t.hm1);
-        ax = __builtin_amdgcn_fractf(cx);  // v_fract_f32: x - floor(x), kept below 1
+        ax = __builtin_amdgcn_fractf(cx);
         ay = __builtin_amdgcn_fractf(cy);
-        const int off = texel_offset(floor_to_int(cy), floor_to_int(cx), t.pitch);
-        r0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(t.rsrc, off, 0, 0));
-        r1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(t.rsrc, off, t.row_bytes, 0));
+        const int off = texel_offset(floor_to_int(cy), floor_to_int(cx), t.pitch) << 2;
+        q = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(t.rsrc, off, 0, 0));
     }
     PM_DEV float value() const {
-        const float top = __builtin_fmaf(ax, r0.y - r0.x, r0.x);
-        const float bot = __builtin_fmaf(ax, r1.y - r1.x, r1.x);
+        const float top = __builtin_fmaf(ax, q.y - q.x, q.x);
+        const float bot = __builtin_fmaf(ax, q.w - q.z, q.z);
         return __builtin_fmaf(ay, bot - top, top);
     }
 };
-
 template <>
 struct BilinearTap<true> {
     float ax, ay;

@@ -583,12 +583,12 @@ __global__ void k_pack_quads(const float* __restrict__ src, int w, int h, uint32
     dst[(long)y * w + x] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
 }
 
-// dense w x h image -> (w+1) x (h+1) image with the last row and column replicated
-__global__ void k_extend(const float* __restrict__ src, int w, int h, float* __restrict__ dst) {
+// dense w x h image -> w x h float4 texels packing the 2x2 bilinear footprint (SrcTex)
+__global__ void k_pack_quads_f32(const float* __restrict__ src, int w, int h, float4* __restrict__ dst) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x > w || y > h) return;
-    const int sx = x > w - 1 ? w - 1 : x, sy = y > h - 1 ? h - 1 : y;
-    dst[(long)y * (w + 1) + x] = src[(long)sy * w + sx];
+    if (x >= w || y >= h) return;
+    const int x1 = x + 1 > w - 1 ? w - 1 : x + 1, y1 = y + 1 > h - 1 ? h - 1 : y + 1;
+    dst[(long)y * w + x] = make_float4(src[(long)y * w + x], src[(long)y * w + x1], src[(long)y1 * w + x], src[(long)y1 * w + x1]);
 }
 
 __global__ void k_export_depth(const float4* __restrict__ planes, float* __restrict__ out, int n) {
