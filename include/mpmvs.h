@@ -154,18 +154,30 @@ int mpmvs_rng(uint64_t seed, uint32_t pix, uint32_t launch_id, int n, void* out)
 /* RunFusion's per-pixel consistency check and averaging (src/PatchMatch.cpp:287-504) in
  * the deterministic "snapshot" formulation of DESIGN.md section 8.  Image k has
  * cams[k] (width/height = size of its maps), depths[k] (fp32), normals[k] (3 fp32 per
- * pixel, world frame), gray[k] (fp32 intensity used as colour), estimate[k] (0 = skip),
+ * pixel, world frame), colors[k] (8-bit, color_channels = 3: interleaved B,G,R as the
+ * reference's cv::Vec3b image, :324; or 1: grey, replicated), estimate[k] (0 = skip),
  * and the view list src_ids[src_off[k] .. src_off[k+1]) whose first entry is k itself
- * (Scene::srcID).  Outputs per image: out_valid (1 where a fused point was produced),
- * out_points9 (x y z nx ny nz r g b per pixel), out_masks (pixels consumed by points of
- * other images).  Host buffers in and out. */
+ * (Scene::srcID).  sky may be NULL, or hold per image NULL or an 8-bit mask of the map's
+ * size: pixels with sky > 0 are masked when their image is fused (:385-388).
+ * Outputs per image: out_valid (1 where a fused point was produced), out_points9
+ * (x y z nx ny nz c0 c1 c2 per pixel, colour in the input channel order), out_masks
+ * (pixels consumed by points of other images, and sky pixels).  Host buffers in and out. */
 int mpmvs_fuse(int device, int n, const mpmvs_camera* cams, const int* estimate, const float* const* depths,
-               const float* const* normals, const float* const* gray, const int* src_off, const int* src_ids,
-               int use_dynamic_consistency, unsigned char* const* out_valid, float* const* out_points9,
-               unsigned char* const* out_masks);
+               const float* const* normals, const unsigned char* const* colors, int color_channels,
+               const unsigned char* const* sky, const int* src_off, const int* src_ids, int use_dynamic_consistency,
+               unsigned char* const* out_valid, float* const* out_points9, unsigned char* const* out_masks);
 
 /* device time (ms, HIP events) of the kernels of the last mpmvs_fuse call */
 float mpmvs_fuse_kernel_ms(void);
+
+/* ---- sky-mask refinement --------------------------------------- */
+/* The device half of bilateral_filter (SkySegment/src/SkyRegionDetect.cu:36-66: the
+ * allocations, copies and the Pixel_bilateral_filter launch, :3-34): bgr is the 8-bit
+ * B,G,R image (height x width x 3), mask the coarse sky probability already resized to
+ * the image (fp32, height x width), out receives 255.0f / 0.0f per pixel.  Host buffers. */
+int mpmvs_sky_bilateral(int device, const unsigned char* bgr, const float* mask, float* out, int height, int width);
+/* device time (ms, HIP events) of the kernel of the last mpmvs_sky_bilateral call */
+float mpmvs_sky_kernel_ms(void);
 
 /* ---- resident texture format ---------------------------------------------- */
 /* Source images whose pixels are all integers in [0, 255] (the reference's

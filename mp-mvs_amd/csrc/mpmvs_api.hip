@@ -22,6 +22,7 @@
 
 #include "../../include/mpmvs.h"
 #include "pm_fusion.hpp"
+#include "pm_sky.hpp"
 #include "pm_kernels.hpp"
 
 using namespace pm;
@@ -693,9 +694,9 @@ float mpmvs_fuse_kernel_ms(void) { return g_fuse_kernel_ms; }
 
 // depth-map fusion, snapshot formulation (pm_fusion.hpp); host buffers in and out
 int mpmvs_fuse(int device, int n, const mpmvs_camera* cams, const int* estimate, const float* const* depths, const float* const* normals,
-               const float* const* gray, const int* src_off, const int* src_ids, int use_dynamic, unsigned char* const* out_valid,
-               float* const* out_points9, unsigned char* const* out_masks) {
-    if (n <= 0 || hipSetDevice(device) != hipSuccess) return -1;
+               const unsigned char* const* colors, int color_channels, const unsigned char* const* sky, const int* src_off, const int* src_ids,
+               int use_dynamic, unsigned char* const* out_valid, float* const* out_points9, unsigned char* const* out_masks) {
+    if (n <= 0 || (color_channels != 1 && color_channels != 3) || hipSetDevice(device) != hipSuccess) return -1;
     std::vector<FuseView> hv(n);
     std::vector<void*> to_free;
     auto dalloc = [&](size_t bytes) -> void* {
@@ -716,19 +717,23 @@ int mpmvs_fuse(int device, int n, const mpmvs_camera* cams, const int* estimate,
         v.h = cams[i].height;
         float* dd = (float*)dalloc(wh * 4);
         float* dn = (float*)dalloc(wh * 12);
-        float* dg = (float*)dalloc(wh * 4);
+        unsigned char* dg = (unsigned char*)dalloc(wh * color_channels);
+        unsigned char* dsky = (sky && sky[i]) ? (unsigned char*)dalloc(wh) : nullptr;
         d_mask[i] = (unsigned char*)dalloc(wh);
         d_next[i] = (unsigned char*)dalloc(wh);
         d_valid[i] = (unsigned char*)dalloc(wh);
         d_out[i] = (float*)dalloc(wh * 36);
-        if (!dd || !dn || !dg || !d_mask[i] || !d_next[i] || !d_valid[i] || !d_out[i]) { rc = -100; break; }
+        if (!dd || !dn || !dg || (sky && sky[i] && !dsky) || !d_mask[i] || !d_next[i] || !d_valid[i] || !d_out[i]) { rc = -100; break; }
         if (hipMemcpy(dd, depths[i], wh * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dn, normals[i], wh * 12, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(dg, gray[i], wh * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemset(d_mask[i], 0, wh) != hipSuccess ||
+            hipMemcpy(dg, colors[i], wh * color_channels, hipMemcpyHostToDevice) != hipSuccess || (dsky && hipMemcpy(dsky, sky[i], wh, hipMemcpyHostToDevice) != hipSuccess) ||
+            hipMemset(d_mask[i], 0, wh) != hipSuccess ||
             hipMemset(d_next[i], 0, wh) != hipSuccess || hipMemset(d_valid[i], 0, wh) != hipSuccess || hipMemset(d_out[i], 0, wh * 36) != hipSuccess)
             rc = -100;
         v.depth = dd;
         v.normal = dn;
-        v.gray = dg;
+        v.color = dg;
+        v.cch = color_channels;
+        v.sky = dsky;
         v.mask = d_mask[i];
         v.mask_next = d_next[i];
     }
@@ -770,6 +775,39 @@ int mpmvs_fuse(int device, int n, const mpmvs_camera* cams, const int* estimate,
             rc = -100;
     }
     for (void* p : to_free) (void)hipFree(p);
+    return rc;
+}
+
+static float g_sky_kernel_ms = 0.0f;
+float mpmvs_sky_kernel_ms(void) { return g_sky_kernel_ms; }
+
+// joint-bilateral sky-mask refinement (pm_sky.hpp); host buffers in and out
+int mpmvs_sky_bilateral(int device, const unsigned char* bgr, const float* mask, float* out, int height, int width) {
+    if (!bgr || !mask || !out || height <= 0 || width <= 0 || hipSetDevice(device) != hipSuccess) return -1;
+    const size_t wh = (size_t)height * width;
+    unsigned char* d_img = nullptr;
+    float *d_mask = nullptr, *d_out = nullptr;
+    int rc = 0;
+    if (hipMalloc(&d_img, wh * 3) != hipSuccess || hipMalloc(&d_mask, wh * 4) != hipSuccess || hipMalloc(&d_out, wh * 4) != hipSuccess) rc = -100;
+    if (!rc && (hipMemcpy(d_img, bgr, wh * 3, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_mask, mask, wh * 4, hipMemcpyHostToDevice) != hipSuccess)) rc = -100;
+    if (!rc) {
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        (void)hipEventCreate(&ev0);
+        (void)hipEventCreate(&ev1);
+        (void)hipEventRecord(ev0, nullptr);
+        const dim3 grid((width + kSkyTW - 1) / kSkyTW, (height + kSkyTH - 1) / kSkyTH);
+        hipLaunchKernelGGL(k_sky_bilateral, grid, dim3(256), 0, nullptr, d_img, d_mask, d_out, height, width);
+        if (hipGetLastError() != hipSuccess) rc = -100;
+        (void)hipEventRecord(ev1, nullptr);
+        if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -100;
+        if (!rc) (void)hipEventElapsedTime(&g_sky_kernel_ms, ev0, ev1);
+        (void)hipEventDestroy(ev0);
+        (void)hipEventDestroy(ev1);
+    }
+    if (!rc && hipMemcpy(out, d_out, wh * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = -100;
+    (void)hipFree(d_img);
+    (void)hipFree(d_mask);
+    (void)hipFree(d_out);
     return rc;
 }
 

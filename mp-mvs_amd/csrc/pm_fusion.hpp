@@ -20,9 +20,11 @@ struct FuseView {
     int w, h;
     const float* depth;
     const float* normal;  // 3 floats per pixel (world)
-    const float* gray;
-    const unsigned char* mask;  // snapshot read by the kernel
-    unsigned char* mask_next;   // marks written by the kernel
+    const unsigned char* color;  // 8-bit, cch interleaved channels (1 = grey, 3 = B,G,R as cv::Vec3b)
+    int cch;
+    const unsigned char* sky;    // optional sky mask (> 0 = sky, reference :385-388) or null
+    unsigned char* mask;         // snapshot read by the kernel (written only at a thread's own sky pixel)
+    unsigned char* mask_next;    // marks written by the kernel
 };
 
 // reference src/PatchMatch.cpp:211-231
@@ -47,6 +49,16 @@ PM_DEV bool round_index(float v, int& out) {
 
 constexpr int kMaxFuseNgb = kMaxViews + 1;
 
+PM_DEV void load_color(const FuseView& V, size_t idx, float& c0, float& c1, float& c2) {
+    if (V.cch == 3) {
+        c0 = (float)V.color[idx * 3];
+        c1 = (float)V.color[idx * 3 + 1];
+        c2 = (float)V.color[idx * 3 + 2];
+    } else {
+        c0 = c1 = c2 = (float)V.color[idx];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_fuse(const FuseView* __restrict__ views, int i, const int* __restrict__ src_ids, int num_ngb,
                                               int use_dynamic, unsigned char* __restrict__ out_valid, float* __restrict__ out9) {
     const FuseView& R = views[i];
@@ -54,13 +66,19 @@ __global__ __launch_bounds__(256) void k_fuse(const FuseView* __restrict__ views
     if (c >= R.w || r >= R.h) return;
     const size_t pix = (size_t)r * R.w + c;
     if (R.mask[pix] == 1) return;
+    if (R.sky && R.sky[pix] > 0) {  // only this thread ever reads mask[pix] of the image being fused
+        R.mask[pix] = 1;
+        R.mask_next[pix] = 1;
+        return;
+    }
     const float ref_depth = R.depth[pix];
     if (ref_depth <= 0.0f) return;
     const float n0 = R.normal[pix * 3], n1 = R.normal[pix * 3 + 1], n2 = R.normal[pix * 3 + 2];
     float X0, X1, X2;
     point_on_world(R.cam, c, r, ref_depth, X0, X1, X2);
     float sp0 = X0, sp1 = X1, sp2 = X2, sn0 = n0, sn1 = n1, sn2 = n2;
-    float scol = R.gray[pix];
+    float sc0, sc1, sc2;
+    load_color(R, pix, sc0, sc1, sc2);
     int num = 0;
     float dyn = 0.0f;
     int used[kMaxFuseNgb];
@@ -99,7 +117,11 @@ __global__ __launch_bounds__(256) void k_fuse(const FuseView* __restrict__ views
             sn0 += m0;
             sn1 += m1;
             sn2 += m2;
-            scol += S.gray[sidx];
+            float g0, g1, g2;
+            load_color(S, sidx, g0, g1, g2);
+            sc0 += g0;
+            sc1 += g1;
+            sc2 += g2;
             const float idx = (err + 200.0f * rel) + angle * 10.0f;
             dyn += d_exp(-idx);
             num++;
@@ -115,10 +137,9 @@ __global__ __launch_bounds__(256) void k_fuse(const FuseView* __restrict__ views
     o[3] = sn0 / d;
     o[4] = sn1 / d;
     o[5] = sn2 / d;
-    const float col = scol / d;
-    o[6] = col;
-    o[7] = col;
-    o[8] = col;
+    o[6] = sc0 / d;
+    o[7] = sc1 / d;
+    o[8] = sc2 / d;
     out_valid[pix] = 1;
     for (int j = 1; j < num_ngb; ++j)
         if (used[j] != -1) views[src_ids[j]].mask_next[used[j]] = 1;  // idempotent

@@ -10,20 +10,34 @@ from ._abi import Camera
 
 _PP_F = C.POINTER(C.POINTER(C.c_float))
 _PP_U8 = C.POINTER(C.POINTER(C.c_ubyte))
-FUSE_ARGTYPES_TAIL = [C.c_int, C.POINTER(Camera), C.POINTER(C.c_int), _PP_F, _PP_F, _PP_F, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
-                      _PP_U8, _PP_F, _PP_U8]
+FUSE_ARGTYPES_TAIL = [C.c_int, C.POINTER(Camera), C.POINTER(C.c_int), _PP_F, _PP_F, _PP_U8, C.c_int, _PP_U8, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                      C.c_int, _PP_U8, _PP_F, _PP_U8]
 
 
-def call_fuse(fn, lead_args, cams, estimate, depths, normals, grays, sources, use_dynamic=True):
-    """fn(*lead_args, n, cams, estimate, depths, normals, gray, src_off, src_ids, use_dynamic, valid, points9, masks)
+def _as_u8(x):
+    x = np.asarray(x)
+    return np.ascontiguousarray(x if x.dtype == np.uint8 else np.clip(np.rint(x), 0, 255).astype(np.uint8))
+
+
+def call_fuse(fn, lead_args, cams, estimate, depths, normals, colors, sources, use_dynamic=True, sky=None):
+    """fn(*lead_args, n, cams, estimate, depths, normals, colors, channels, sky, src_off, src_ids, use_dynamic, valid, points9, masks)
+    colors[k]: HxW grey or HxWx3 B,G,R (8 bit; floats are rounded); sky: None or per image None / HxW uint8 mask;
     sources[k] = source-view ids of image k (without k itself).  Returns
     (points [M, 9] in image-then-raster order, valid list, masks list)."""
     n = len(cams)
     d = [np.ascontiguousarray(x, np.float32) for x in depths]
     nm = [np.ascontiguousarray(x, np.float32) for x in normals]
-    g = [np.ascontiguousarray(x, np.float32) for x in grays]
+    g = [_as_u8(x) for x in colors]
+    cch = 3 if (n and g[0].ndim == 3) else 1
     for k in range(n):
-        assert d[k].shape == (cams[k].height, cams[k].width) and nm[k].shape == d[k].shape + (3,) and g[k].shape == d[k].shape
+        assert d[k].shape == (cams[k].height, cams[k].width) and nm[k].shape == d[k].shape + (3,)
+        assert g[k].shape == (d[k].shape + (3,) if cch == 3 else d[k].shape)
+    skyp = None
+    if sky is not None:
+        sk = [None if m is None else _as_u8(m) for m in sky]
+        for k in range(n):
+            assert sk[k] is None or sk[k].shape == d[k].shape
+        skyp = (C.POINTER(C.c_ubyte) * n)(*[None if m is None else m.ctypes.data_as(C.POINTER(C.c_ubyte)) for m in sk])
     ids, off = [], [0]
     for k in range(n):
         ids += [k] + list(sources[k])
@@ -33,7 +47,7 @@ def call_fuse(fn, lead_args, cams, estimate, depths, normals, grays, sources, us
     masks = [np.zeros(x.shape, np.uint8) for x in d]
     fp = lambda arrs: (C.POINTER(C.c_float) * n)(*[a.ctypes.data_as(C.POINTER(C.c_float)) for a in arrs])
     up = lambda arrs: (C.POINTER(C.c_ubyte) * n)(*[a.ctypes.data_as(C.POINTER(C.c_ubyte)) for a in arrs])
-    rc = fn(*lead_args, n, (Camera * n)(*cams), (C.c_int * n)(*[1 if e else 0 for e in estimate]), fp(d), fp(nm), fp(g),
+    rc = fn(*lead_args, n, (Camera * n)(*cams), (C.c_int * n)(*[1 if e else 0 for e in estimate]), fp(d), fp(nm), up(g), cch, skyp,
             (C.c_int * (n + 1))(*off), (C.c_int * len(ids))(*ids), 1 if use_dynamic else 0, up(valid), fp(pts), up(masks))
     if rc != 0:
         raise RuntimeError(f"fuse failed ({rc})")
@@ -41,14 +55,14 @@ def call_fuse(fn, lead_args, cams, estimate, depths, normals, grays, sources, us
     return cloud, valid, masks
 
 
-def fuse(cams, estimate, depths, normals, grays, sources, use_dynamic=True, device=0):
+def fuse(cams, estimate, depths, normals, colors, sources, use_dynamic=True, device=0, sky=None):
     """fusion on the MI355X (mpmvs_fuse)"""
     from . import engine
     lib, _ = engine.load()
     fn = lib.mpmvs_fuse
     fn.restype = C.c_int
     fn.argtypes = [C.c_int] + FUSE_ARGTYPES_TAIL
-    return call_fuse(fn, (int(device),), cams, estimate, depths, normals, grays, sources, use_dynamic)
+    return call_fuse(fn, (int(device),), cams, estimate, depths, normals, colors, sources, use_dynamic, sky)
 
 
 def last_kernel_ms():
@@ -56,3 +70,29 @@ def last_kernel_ms():
     lib, _ = engine.load()
     lib.mpmvs_fuse_kernel_ms.restype = C.c_float
     return float(lib.mpmvs_fuse_kernel_ms())
+
+
+def sky_bilateral(bgr, mask, device=0):
+    """joint-bilateral refinement of a coarse sky-probability mask on the MI355X (mpmvs_sky_bilateral;
+    reference SkySegment/src/SkyRegionDetect.cu:3-66).  bgr: HxWx3 uint8, mask: HxW fp32 -> HxW fp32 of 255 / 0"""
+    from . import engine
+    lib, _ = engine.load()
+    fn = lib.mpmvs_sky_bilateral
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    mask = np.ascontiguousarray(mask, np.float32)
+    if bgr.shape != mask.shape + (3,):
+        raise ValueError("bgr must be HxWx3 and mask HxW")
+    out = np.empty(mask.shape, np.float32)
+    rc = fn(int(device), bgr.ctypes.data, mask.ctypes.data, out.ctypes.data, mask.shape[0], mask.shape[1])
+    if rc != 0:
+        raise RuntimeError(f"mpmvs_sky_bilateral failed ({rc})")
+    return out
+
+
+def last_sky_kernel_ms():
+    from . import engine
+    lib, _ = engine.load()
+    lib.mpmvs_sky_kernel_ms.restype = C.c_float
+    return float(lib.mpmvs_sky_kernel_ms())

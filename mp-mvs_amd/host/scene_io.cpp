@@ -6,11 +6,12 @@
 // reads images + cameras (+ the previous pass's depths/normals/costs.dmb for
 // geometric consistency), runs the in-memory ProcessProblem, writes
 // depths.dmb / normals.dmb / costs.dmb under <output>/2333_<id>.
-// Images: the reference reads <input>/images/%08d.jpg through OpenCV; no JPEG
-// decoder exists on the target image (row f-3), so this build reads the same
-// name with extension .pgm (binary P5, 8 bit) -- `mogrify -format pgm *.jpg`.
+// Images: the reference reads <input>/images/%08d.jpg through OpenCV; here the same
+// files are read by the decoder of jpeg_decode.h (row f-3); binary PGM / PPM files of
+// the same name are accepted as well.
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cstdio>
 #include <cstring>
@@ -19,7 +20,10 @@
 #include <iostream>
 #include <sstream>
 
+#include <cmath>
+
 #include "PatchMatch.h"
+#include "jpeg_decode.h"
 #include "scene_io.h"
 
 // ---------------------------------------------------------------------------
@@ -122,39 +126,124 @@ void GenerateSampleList(const std::string& input_folder, int maxSourceImageNum, 
 }
 
 // ---------------------------------------------------------------------------
-// images (binary PGM stands in for the reference's JPEG, see header comment)
+// images: JPEG through the own decoder, or binary PGM / PPM
 // ---------------------------------------------------------------------------
-bool readGrayImage(const std::string& path, Image& img) {
+static bool read_file(const std::string& path, std::vector<unsigned char>& buf) {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return false;
-    char magic[3] = {0, 0, 0};
-    int w = 0, h = 0, maxv = 0;
-    auto next_int = [&](int& v) {
-        int c = fgetc(f);
-        while (c == '#' || c == ' ' || c == '\n' || c == '\r' || c == '\t') {
-            if (c == '#')
-                while (c != '\n' && c != EOF) c = fgetc(f);
-            c = fgetc(f);
-        }
-        if (c < '0' || c > '9') return false;
-        v = 0;
-        while (c >= '0' && c <= '9') {
-            v = v * 10 + (c - '0');
-            c = fgetc(f);
-        }
-        return true;  // the single whitespace after the number has been consumed
-    };
-    bool ok = fread(magic, 1, 2, f) == 2 && magic[0] == 'P' && magic[1] == '5' && next_int(w) && next_int(h) && next_int(maxv) && maxv == 255 && w > 0 && h > 0;
-    if (ok) {
-        std::vector<unsigned char> buf((size_t)w * h);
-        ok = fread(buf.data(), 1, buf.size(), f) == buf.size();
-        if (ok) {
-            img = Image(h, w, 1);
-            for (size_t i = 0; i < buf.size(); ++i) img.data[i] = (float)buf[i];  // convertTo(CV_32FC1), reference :882
-        }
-    }
+    fseek(f, 0, SEEK_END);
+    const long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    buf.resize(n > 0 ? (size_t)n : 0);
+    const bool ok = n > 0 && fread(buf.data(), 1, buf.size(), f) == buf.size();
     fclose(f);
     return ok;
+}
+
+// binary PNM body: P5 (1 channel) or P6 (3 channels, R,G,B), maxval 255
+static bool parse_pnm(const std::vector<unsigned char>& buf, Image8& img) {
+    if (buf.size() < 7 || buf[0] != 'P' || (buf[1] != '5' && buf[1] != '6')) return false;
+    size_t i = 2;
+    auto next_int = [&](int& v) {
+        while (i < buf.size() && (buf[i] == '#' || buf[i] == ' ' || buf[i] == '\n' || buf[i] == '\r' || buf[i] == '\t')) {
+            if (buf[i] == '#')
+                while (i < buf.size() && buf[i] != '\n') ++i;
+            else
+                ++i;
+        }
+        if (i >= buf.size() || buf[i] < '0' || buf[i] > '9') return false;
+        v = 0;
+        while (i < buf.size() && buf[i] >= '0' && buf[i] <= '9') v = v * 10 + (buf[i++] - '0');
+        return true;
+    };
+    int w = 0, h = 0, maxv = 0;
+    if (!next_int(w) || !next_int(h) || !next_int(maxv) || maxv != 255 || w <= 0 || h <= 0) return false;
+    ++i;  // the single whitespace after maxval
+    const int ch = buf[1] == '6' ? 3 : 1;
+    const size_t need = (size_t)w * h * ch;
+    if (i + need > buf.size()) return false;
+    img.rows = h;
+    img.cols = w;
+    img.ch = ch;
+    img.data.assign(buf.begin() + i, buf.begin() + i + need);
+    return true;
+}
+
+static bool read_image8(const std::string& path, int channels, Image8& img) {
+    std::vector<unsigned char> buf;
+    if (!read_file(path, buf)) return false;
+    if (buf.size() > 2 && buf[0] == 0xFF && buf[1] == 0xD8) {
+        std::string err;
+        int w = 0, h = 0;
+        if (!DecodeJpeg(buf.data(), buf.size(), channels, img.data, w, h, err)) {
+            std::cout << "JPEG decode failed for " << path << ": " << err << std::endl;
+            return false;
+        }
+        img.rows = h;
+        img.cols = w;
+        img.ch = channels;
+        return true;
+    }
+    Image8 raw;
+    if (!parse_pnm(buf, raw)) return false;
+    const size_t n = (size_t)raw.rows * raw.cols;
+    img.rows = raw.rows;
+    img.cols = raw.cols;
+    img.ch = channels;
+    if (raw.ch == channels) {
+        img.data.swap(raw.data);
+        if (channels == 3)  // P6 is R,G,B
+            for (size_t k = 0; k < n; ++k) std::swap(img.data[3 * k], img.data[3 * k + 2]);
+    } else if (channels == 3) {
+        img.data.resize(n * 3);
+        for (size_t k = 0; k < n; ++k) img.data[3 * k] = img.data[3 * k + 1] = img.data[3 * k + 2] = raw.data[k];
+    } else {
+        // OpenCV's 8-bit BGR2GRAY: (B*1868 + G*9617 + R*4899 + 8192) >> 14
+        img.data.resize(n);
+        for (size_t k = 0; k < n; ++k)
+            img.data[k] = (unsigned char)((raw.data[3 * k + 2] * 1868 + raw.data[3 * k + 1] * 9617 + raw.data[3 * k] * 4899 + 8192) >> 14);
+    }
+    return true;
+}
+
+bool readGrayImage(const std::string& path, Image& img) {
+    Image8 g;
+    if (!read_image8(path, 1, g)) return false;
+    img = Image(g.rows, g.cols, 1);
+    for (size_t i = 0; i < g.data.size(); ++i) img.data[i] = (float)g.data[i];  // convertTo(CV_32FC1), reference :882
+    return true;
+}
+
+bool readColorImage(const std::string& path, Image8& bgr) { return read_image8(path, 3, bgr); }
+
+bool writeGrayImage(const std::string& path, const Image8& img) {
+    if (img.ch != 1) return false;
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    fprintf(f, "P5\n%d %d\n255\n", img.cols, img.rows);
+    const bool ok = fwrite(img.data.data(), 1, img.data.size(), f) == img.data.size();
+    fclose(f);
+    return ok;
+}
+
+// cv::resize(INTER_LINEAR) of an 8-bit image: channel-wise through the fp32 ResizeLinear, rounded to nearest
+// (OpenCV's 8-bit path uses 11-bit fixed-point weights; the two can differ by one grey level)
+Image8 ResizeLinear8(const Image8& src, int new_cols, int new_rows) {
+    Image8 out;
+    out.rows = new_rows;
+    out.cols = new_cols;
+    out.ch = src.ch;
+    out.data.resize((size_t)new_rows * new_cols * src.ch);
+    for (int k = 0; k < src.ch; ++k) {
+        Image plane(src.rows, src.cols, 1);
+        for (size_t i = 0; i < plane.data.size(); ++i) plane.data[i] = (float)src.data[i * src.ch + k];
+        const Image r = ResizeLinear(plane, new_cols, new_rows);
+        for (size_t i = 0; i < r.data.size(); ++i) {
+            const float v = std::nearbyintf(r.data[i]);
+            out.data[i * src.ch + k] = (unsigned char)(v < 0.0f ? 0.0f : v > 255.0f ? 255.0f : v);
+        }
+    }
+    return out;
 }
 
 static std::string id8(int id) {
@@ -162,6 +251,16 @@ static std::string id8(int id) {
     s << std::setw(8) << std::setfill('0') << id;
     return s.str();
 }
+
+static std::string find_with_ext(const std::string& stem) {
+    for (const char* ext : {".jpg", ".jpeg", ".JPG", ".ppm", ".pgm"}) {
+        struct stat st;
+        if (stat((stem + ext).c_str(), &st) == 0) return stem + ext;
+    }
+    return "";
+}
+
+std::string FindImageFile(const std::string& image_folder, int id) { return find_with_ext(image_folder + "/" + id8(id)); }
 
 // reference src/PatchMatch.cpp:506-638 with its file traffic
 void ProcessProblem(const std::string& input_folder, const std::string& output_folder, std::vector<Scene>& Scenes, const int ID,
@@ -174,8 +273,8 @@ void ProcessProblem(const std::string& input_folder, const std::string& output_f
     for (int sid : scene.srcID) {
         Scene& s = Scenes[sid];
         if (s.image.empty()) {
-            if (!readGrayImage(input_folder + "/images/" + id8(sid) + ".pgm", s.image)) {
-                std::cout << "Can not read this image !" << input_folder + "/images/" + id8(sid) + ".pgm" << std::endl;
+            if (!readGrayImage(FindImageFile(input_folder + "/images", sid), s.image)) {
+                std::cout << "Can not read this image !" << input_folder + "/images/" + id8(sid) + ".jpg" << std::endl;
                 exit(EXIT_FAILURE);
             }
             s.cam = ReadCamera(input_folder + "/cams/" + id8(sid) + "_cam.txt");
@@ -230,33 +329,89 @@ void StoreColorPlyFileBinaryPointCloud(const std::string& plyFilePath, const std
 }
 
 // ---------------------------------------------------------------------------
+// sky masks (reference src/PatchMatch.cpp:4-57, SkySegment/src/SkyRegionDetect.cu:36-66)
+// ---------------------------------------------------------------------------
+bool bilateral_filter(const Image8& img, const Image& mask, Image& result, int device) {
+    if (img.ch != 3 || img.empty() || mask.empty()) return false;
+    const Image m2 = (mask.rows != img.rows || mask.cols != img.cols) ? ResizeLinear(mask, img.cols, img.rows) : mask;
+    result = Image(img.rows, img.cols, 1);
+    return mpmvs_sky_bilateral(device, img.data.data(), m2.data.data(), result.data.data(), img.rows, img.cols) == 0;
+}
+
+int RefineSkyMasks(const std::string& input_folder, const std::vector<Scene>& Scenes, int max_image_size, int device) {
+    int written = 0;
+    for (const Scene& s : Scenes) {
+        Image8 bgr, coarse8;
+        if (!readColorImage(FindImageFile(input_folder + "/images", s.refID), bgr)) return -1;
+        const std::string res = input_folder + "/MPMVS/2333_" + id8(s.refID);
+        const std::string coarse_file = find_with_ext(res + "/skymask");
+        if (coarse_file.empty() || !read_image8(coarse_file, 1, coarse8)) {
+            std::cout << "Can not read the coarse sky mask " << res << "/skymask.*" << std::endl;
+            return -1;
+        }
+        int w = bgr.cols, h = bgr.rows;
+        if (bgr.cols > max_image_size || bgr.rows > max_image_size) {  // reference :24-32
+            const float factor = std::min((float)max_image_size / bgr.cols, (float)max_image_size / bgr.rows);
+            w = (int)std::round(bgr.cols * factor);
+            h = (int)std::round(bgr.rows * factor);
+            bgr = ResizeLinear8(bgr, w, h);
+        }
+        Image coarse(coarse8.rows, coarse8.cols, 1);
+        for (size_t i = 0; i < coarse.data.size(); ++i) coarse.data[i] = (float)coarse8.data[i] / 255.0f;  // the file holds 255 * probability (:44)
+        Image refined;
+        if (!bilateral_filter(bgr, coarse, refined, device)) return -1;
+        Image8 out;
+        out.rows = h;
+        out.cols = w;
+        out.ch = 1;
+        out.data.resize(refined.data.size());
+        for (size_t i = 0; i < refined.data.size(); ++i) out.data[i] = refined.data[i] > 0.0f ? 255 : 0;
+        mkdir((input_folder + "/MPMVS").c_str(), 0777);
+        mkdir(res.c_str(), 0777);
+        if (!writeGrayImage(res + "/skymask_refine.pgm", out)) return -1;
+        ++written;
+    }
+    return written;
+}
+
+// ---------------------------------------------------------------------------
 // RunFusion over a dataset folder (reference src/PatchMatch.cpp:287-504): reads every
-// estimated image's depths.dmb / normals.dmb, camera and image, fuses them on the GPU
-// (mpmvs_fuse, the snapshot formulation of DESIGN.md section 8) and writes
-// <output>/MPMVS_model.ply.  Colour = the grey value (this build reads grey PGM images).
+// estimated image's depths.dmb / normals.dmb, camera and colour image (B,G,R), and with
+// sky_seg its skymask_refine image (:360-372, :385-388), fuses them on the GPU (mpmvs_fuse,
+// the snapshot formulation of DESIGN.md section 8) and writes <output>/MPMVS_model.ply.
 // Returns the number of points, or -1.
 // ---------------------------------------------------------------------------
-long RunFusion(const std::string& input_folder, const std::string& output_folder, std::vector<Scene>& Scenes, bool use_dynamic_consistency, int device) {
+long RunFusion(const std::string& input_folder, const std::string& output_folder, std::vector<Scene>& Scenes, bool use_dynamic_consistency, int device,
+               bool sky_seg) {
     const int n = (int)Scenes.size();
     std::vector<Camera> cams(n);
     std::vector<int> estimate(n, 0), src_off(1, 0), src_ids;
-    std::vector<Image> depths(n), normals(n), grays(n);
+    std::vector<Image> depths(n), normals(n);
+    std::vector<Image8> colors(n), sky(n);
     for (int i = 0; i < n; ++i) {
         Scene& s = Scenes[i];
         if (s.estimate) {
             std::cout << "Reading image " << id8(i) << "..." << std::endl;
             const std::string res = input_folder + "/MPMVS/2333_" + id8(s.refID);
             if (!readDepthDmb(res + "/depths.dmb", depths[i]) || !readNormalDmb(res + "/normals.dmb", normals[i])) return -1;
-            if (s.image.empty() && !readGrayImage(input_folder + "/images/" + id8(s.refID) + ".pgm", s.image)) return -1;
+            if (!readColorImage(FindImageFile(input_folder + "/images", s.refID), colors[i])) return -1;
             cams[i] = ReadCamera(input_folder + "/cams/" + id8(s.refID) + "_cam.txt");
-            grays[i] = s.image;
-            if (grays[i].rows != depths[i].rows || grays[i].cols != depths[i].cols) {  // RescaleImageAndCamera, reference :262-284
-                const float sx = depths[i].cols / (float)grays[i].cols, sy = depths[i].rows / (float)grays[i].rows;
-                grays[i] = ResizeLinear(grays[i], depths[i].cols, depths[i].rows);
+            if (colors[i].rows != depths[i].rows || colors[i].cols != depths[i].cols) {  // RescaleImageAndCamera, reference :262-284
+                const float sx = depths[i].cols / (float)colors[i].cols, sy = depths[i].rows / (float)colors[i].rows;
+                colors[i] = ResizeLinear8(colors[i], depths[i].cols, depths[i].rows);
                 cams[i].K[0] *= sx;
                 cams[i].K[2] *= sx;
                 cams[i].K[4] *= sy;
                 cams[i].K[5] *= sy;
+            }
+            if (sky_seg) {
+                Image8 m;
+                const std::string mask_file = find_with_ext(res + "/skymask_refine");
+                if (mask_file.empty() || !read_image8(mask_file, 1, m)) {
+                    std::cout << "Can not read the sky mask of image " << id8(s.refID) << std::endl;
+                    return -1;
+                }
+                sky[i] = (m.rows != depths[i].rows || m.cols != depths[i].cols) ? ResizeLinear8(m, depths[i].cols, depths[i].rows) : m;
             }
             cams[i].width = depths[i].cols;
             cams[i].height = depths[i].rows;
@@ -267,12 +422,15 @@ long RunFusion(const std::string& input_folder, const std::string& output_folder
             cams[i].width = cams[i].height = 1;
             depths[i] = Image(1, 1, 1);
             normals[i] = Image(1, 1, 3);
-            grays[i] = Image(1, 1, 1);
+            colors[i].rows = colors[i].cols = 1;
+            colors[i].ch = 3;
+            colors[i].data.assign(3, 0);
             src_ids.push_back(i);
         }
         src_off.push_back((int)src_ids.size());
     }
-    std::vector<const float*> dp(n), np_(n), gp(n);
+    std::vector<const float*> dp(n), np_(n);
+    std::vector<const unsigned char*> gp(n), sp(n, nullptr);
     std::vector<std::vector<unsigned char>> valid(n), masks(n);
     std::vector<std::vector<float>> pts(n);
     std::vector<unsigned char*> vp(n), mp(n);
@@ -281,7 +439,8 @@ long RunFusion(const std::string& input_folder, const std::string& output_folder
         const size_t wh = (size_t)cams[i].width * cams[i].height;
         dp[i] = depths[i].data.data();
         np_[i] = normals[i].data.data();
-        gp[i] = grays[i].data.data();
+        gp[i] = colors[i].data.data();
+        if (!sky[i].empty()) sp[i] = sky[i].data.data();
         valid[i].assign(wh, 0);
         masks[i].assign(wh, 0);
         pts[i].assign(wh * 9, 0.0f);
@@ -289,8 +448,8 @@ long RunFusion(const std::string& input_folder, const std::string& output_folder
         mp[i] = masks[i].data();
         pp[i] = pts[i].data();
     }
-    if (mpmvs_fuse(device, n, cams.data(), estimate.data(), dp.data(), np_.data(), gp.data(), src_off.data(), src_ids.data(), use_dynamic_consistency ? 1 : 0,
-                   vp.data(), pp.data(), mp.data()) != 0)
+    if (mpmvs_fuse(device, n, cams.data(), estimate.data(), dp.data(), np_.data(), gp.data(), 3, sky_seg ? sp.data() : nullptr, src_off.data(), src_ids.data(),
+                   use_dynamic_consistency ? 1 : 0, vp.data(), pp.data(), mp.data()) != 0)
         return -1;
     std::vector<PointList> cloud;
     for (int i = 0; i < n; ++i)
@@ -375,11 +534,35 @@ int mpmvs_host_read_pgm(const char* path, float* data, size_t capacity_floats, i
 // and in place (Gauss-Seidel through the files, as the reference does)
 // reference main()'s last step (src/main.cpp:49): fuse the maps of a processed folder into
 // <folder>/MPMVS/MPMVS_model.ply; returns the number of points or -1
-long mpmvs_host_fuse_folder(const char* input_folder, int device, int max_src, int use_dynamic_consistency) {
+long mpmvs_host_fuse_folder(const char* input_folder, int device, int max_src, int use_dynamic_consistency, int sky_seg) {
     std::vector<Scene> Scenes;
     GenerateSampleList(input_folder, max_src, 3200, Scenes);
     const std::string in = input_folder;
-    return RunFusion(in, in + "/MPMVS", Scenes, use_dynamic_consistency != 0, device);
+    return RunFusion(in, in + "/MPMVS", Scenes, use_dynamic_consistency != 0, device, sky_seg != 0);
+}
+int mpmvs_host_refine_sky_masks(const char* input_folder, int device, int max_src, int max_image_size) {
+    std::vector<Scene> Scenes;
+    GenerateSampleList(input_folder, max_src, max_image_size, Scenes);
+    return RefineSkyMasks(input_folder, Scenes, max_image_size, device);
+}
+// cv::imread stand-in for the tests: channels 1 (IMREAD_GRAYSCALE) or 3 (IMREAD_COLOR, B,G,R); call with data = NULL for the size
+int mpmvs_host_read_image(const char* path, int channels, unsigned char* data, size_t capacity, int* h, int* w) {
+    Image8 img;
+    if (!(channels == 3 ? readColorImage(path, img) : read_image8(path, 1, img))) return -1;
+    *h = img.rows;
+    *w = img.cols;
+    if (data && capacity >= img.data.size()) std::memcpy(data, img.data.data(), img.data.size());
+    return 0;
+}
+int mpmvs_host_decode_jpeg(const unsigned char* bytes, size_t size, int channels, unsigned char* data, size_t capacity, int* h, int* w) {
+    std::vector<unsigned char> px;
+    std::string err;
+    if (!DecodeJpeg(bytes, size, channels, px, *w, *h, err)) {
+        std::cout << "JPEG decode failed: " << err << std::endl;
+        return -1;
+    }
+    if (data && capacity >= px.size()) std::memcpy(data, px.data(), px.size());
+    return 0;
 }
 int mpmvs_host_run_folder(const char* input_folder, int device, int max_src, int geom_iterations, int planar_prior,
                           int geomPlanarPrior, int max_scale, uint64_t seed) {

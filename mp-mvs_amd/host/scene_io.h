@@ -24,8 +24,30 @@ struct PointList {
 };
 void StoreColorPlyFileBinaryPointCloud(const std::string& plyFilePath, const std::vector<PointList>& pc);
 // reference RunFusion(const ConfigParams&, const std::vector<Scene>&) (include/PatchMatch.h:85); returns the point count
-long RunFusion(const std::string& input_folder, const std::string& output_folder, std::vector<Scene>& Scenes, bool use_dynamic_consistency, int device = 0);
-bool readGrayImage(const std::string& path, Image& img);  // binary PGM (P5), 8 bit
+long RunFusion(const std::string& input_folder, const std::string& output_folder, std::vector<Scene>& Scenes, bool use_dynamic_consistency, int device = 0,
+               bool sky_seg = false);
+// 8-bit image as cv::imread returns it (interleaved channels; colour = B,G,R)
+struct Image8 {
+    int rows = 0, cols = 0, ch = 1;
+    std::vector<unsigned char> data;
+    bool empty() const { return data.empty(); }
+};
+// cv::imread(path, IMREAD_GRAYSCALE) + convertTo(CV_32F) (reference src/PatchMatch.cpp:877-882): JPEG (own decoder,
+// jpeg_decode.h), binary PGM (P5) or PPM (P6, converted with OpenCV's fixed-point BGR2GRAY weights); format by content
+bool readGrayImage(const std::string& path, Image& img);
+// cv::imread(path, IMREAD_COLOR) (reference :324): JPEG, PPM or PGM -> 3 channels B,G,R
+bool readColorImage(const std::string& path, Image8& bgr);
+bool writeGrayImage(const std::string& path, const Image8& img);  // binary PGM
+// <folder>/%08d with the first existing extension of .jpg .jpeg .JPG .ppm .pgm ("" if none)
+std::string FindImageFile(const std::string& image_folder, int id);
+Image8 ResizeLinear8(const Image8& src, int new_cols, int new_rows);
+// reference SkySegment/include/SkyRegionDetect.h:43 bilateral_filter(img, mask_, result): the coarse probability mask is resized
+// to the image (cv::resize INTER_LINEAR, SkyRegionDetect.cu:40-41) and refined on the GPU (mpmvs_sky_bilateral); result = 255 / 0
+bool bilateral_filter(const Image8& img_bgr, const Image& mask, Image& result, int device = 0);
+// reference GenerateSkyRegionMask (src/PatchMatch.cpp:4-57) without the segmentation network: for every image reads the
+// network's output as the reference stores it, <input>/MPMVS/2333_<id>/skymask.{jpg,pgm} (8 bit = 255 x probability), resizes
+// image and mask as :21-34 do, refines, and writes skymask_refine.pgm (0 / 255) beside it.  Returns the number of masks written or -1.
+int RefineSkyMasks(const std::string& input_folder, const std::vector<Scene>& Scenes, int max_image_size, int device = 0);
 void ProcessProblem(const std::string& input_folder, const std::string& output_folder, std::vector<Scene>& Scenes, const int ID,
                     bool geom_consistency, bool planar_prior, uint64_t seed = 0, int device = 0, int max_scale = 2);
 

@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "host", "libmpmvs_host.so")
 SYMBOLS = ["mpmvs_host_triangulate_vertices", "mpmvs_host_delaunay", "mpmvs_host_build_prior", "mpmvs_host_run_pipeline",
            "mpmvs_host_write_dmb", "mpmvs_host_read_dmb", "mpmvs_host_read_camera", "mpmvs_host_sample_list", "mpmvs_host_read_pgm",
-           "mpmvs_host_run_folder", "mpmvs_host_resize_linear", "mpmvs_host_write_ply", "mpmvs_host_fuse_folder"]
+           "mpmvs_host_run_folder", "mpmvs_host_resize_linear", "mpmvs_host_write_ply", "mpmvs_host_fuse_folder", "mpmvs_host_read_image",
+           "mpmvs_host_decode_jpeg", "mpmvs_host_refine_sky_masks"]
 _cache = {}
 
 
@@ -44,7 +45,13 @@ def load():
         lib.mpmvs_host_run_folder.restype = C.c_int
         lib.mpmvs_host_run_folder.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]
         lib.mpmvs_host_fuse_folder.restype = C.c_long
-        lib.mpmvs_host_fuse_folder.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
+        lib.mpmvs_host_fuse_folder.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        lib.mpmvs_host_refine_sky_masks.restype = C.c_int
+        lib.mpmvs_host_refine_sky_masks.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
+        lib.mpmvs_host_read_image.restype = C.c_int
+        lib.mpmvs_host_read_image.argtypes = [C.c_char_p, C.c_int, P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.mpmvs_host_decode_jpeg.restype = C.c_int
+        lib.mpmvs_host_decode_jpeg.argtypes = [C.c_char_p, C.c_size_t, C.c_int, P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.mpmvs_host_write_ply.restype = C.c_int
         lib.mpmvs_host_write_ply.argtypes = [C.c_char_p, P, C.c_int]
         lib.mpmvs_host_resize_linear.restype = C.c_int
@@ -160,6 +167,28 @@ def read_pgm(path):
     return out
 
 
+def read_image(path, channels=1):
+    """what cv::imread(path, GRAYSCALE / COLOR) hands the reference: uint8 HxW or HxWx3 (B,G,R); JPEG, PGM or PPM"""
+    lib = load()
+    h, w = C.c_int(), C.c_int()
+    if lib.mpmvs_host_read_image(str(path).encode(), channels, None, 0, C.byref(h), C.byref(w)) != 0:
+        raise RuntimeError(f"cannot read {path}")
+    out = np.empty((h.value, w.value) + ((3,) if channels == 3 else ()), np.uint8)
+    lib.mpmvs_host_read_image(str(path).encode(), channels, out.ctypes.data, out.size, C.byref(h), C.byref(w))
+    return out
+
+
+def decode_jpeg(data, channels=1):
+    lib = load()
+    data = bytes(data)
+    h, w = C.c_int(), C.c_int()
+    if lib.mpmvs_host_decode_jpeg(data, len(data), channels, None, 0, C.byref(h), C.byref(w)) != 0:
+        raise RuntimeError("JPEG decode failed")
+    out = np.empty((h.value, w.value) + ((3,) if channels == 3 else ()), np.uint8)
+    lib.mpmvs_host_decode_jpeg(data, len(data), channels, out.ctypes.data, out.size, C.byref(h), C.byref(w))
+    return out
+
+
 def run_folder(folder, device=0, max_src=20, geom_iterations=2, planar_prior=True, geom_planar_prior=True, max_scale=2, seed=12345):
     rc = load().mpmvs_host_run_folder(str(folder).encode(), device, max_src, geom_iterations, 1 if planar_prior else 0,
                                       1 if geom_planar_prior else 0, max_scale, seed)
@@ -167,18 +196,25 @@ def run_folder(folder, device=0, max_src=20, geom_iterations=2, planar_prior=Tru
         raise RuntimeError(f"run_folder failed ({rc})")
 
 
-def write_dataset(folder, cams, images, sources, scores=None):
-    """a scene in the reference's input layout: images/%08d.pgm, cams/%08d_cam.txt
-    (MVSNet style, reference src/PatchMatch.cpp:109-143), pair.txt (reference :67-107)"""
+def write_dataset(folder, cams, images, sources, scores=None, fmt="pgm", jpeg_options=None):
+    """a scene in the reference's input layout: images/%08d.<fmt>, cams/%08d_cam.txt
+    (MVSNet style, reference src/PatchMatch.cpp:109-143), pair.txt (reference :67-107).
+    fmt: "pgm" (grey, HxW), "ppm" (HxWx3 R,G,B) or "jpg" (either; written with PIL, test/tool use only)"""
     import os
     os.makedirs(os.path.join(folder, "images"), exist_ok=True)
     os.makedirs(os.path.join(folder, "cams"), exist_ok=True)
     for i, (cam, img) in enumerate(zip(cams, images)):
         a = np.asarray(img)
-        assert np.array_equal(a, np.rint(a)) and a.min() >= 0 and a.max() <= 255, "PGM holds 8-bit images"
-        with open(os.path.join(folder, "images", f"{i:08d}.pgm"), "wb") as f:
-            f.write(b"P5\n%d %d\n255\n" % (a.shape[1], a.shape[0]))
-            f.write(a.astype(np.uint8).tobytes())
+        assert np.array_equal(a, np.rint(a)) and a.min() >= 0 and a.max() <= 255, "image files hold 8-bit images"
+        path = os.path.join(folder, "images", f"{i:08d}.{fmt}")
+        if fmt == "jpg":
+            from PIL import Image
+            Image.fromarray(a.astype(np.uint8)).save(path, "JPEG", **(jpeg_options or {"quality": 95}))
+        else:
+            assert (fmt == "pgm" and a.ndim == 2) or (fmt == "ppm" and a.ndim == 3)
+            with open(path, "wb") as f:
+                f.write(b"P%d\n%d %d\n255\n" % (5 if fmt == "pgm" else 6, a.shape[1], a.shape[0]))
+                f.write(a.astype(np.uint8).tobytes())
         R, t, K = list(cam.R), list(cam.t), list(cam.K)
         with open(os.path.join(folder, "cams", f"{i:08d}_cam.txt"), "w") as f:
             f.write("extrinsic\n")
@@ -208,9 +244,17 @@ def write_ply(path, points9):
     load().mpmvs_host_write_ply(str(path).encode(), a.ctypes.data, len(a))
 
 
-def fuse_folder(folder, device=0, max_src=20, use_dynamic=True):
+def refine_sky_masks(folder, device=0, max_src=20, max_image_size=3200):
+    """<folder>/MPMVS/2333_<id>/skymask.* (coarse, 255 x probability) -> skymask_refine.pgm; returns the number written"""
+    n = load().mpmvs_host_refine_sky_masks(str(folder).encode(), device, max_src, max_image_size)
+    if n < 0:
+        raise RuntimeError("refine_sky_masks failed")
+    return int(n)
+
+
+def fuse_folder(folder, device=0, max_src=20, use_dynamic=True, sky_seg=False):
     """RunFusion over a processed dataset folder -> <folder>/MPMVS/MPMVS_model.ply; returns the point count"""
-    n = load().mpmvs_host_fuse_folder(str(folder).encode(), device, max_src, 1 if use_dynamic else 0)
+    n = load().mpmvs_host_fuse_folder(str(folder).encode(), device, max_src, 1 if use_dynamic else 0, 1 if sky_seg else 0)
     if n < 0:
         raise RuntimeError("fuse_folder failed")
     return int(n)

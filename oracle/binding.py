@@ -67,7 +67,7 @@ def eval_ncc_literal(handle, params, planes_cam, scale, quantize_fraction=False)
     return out
 
 
-def fuse(cams, estimate, depths, normals, grays, sources, use_dynamic=True, sequential_literal=False):
+def fuse(cams, estimate, depths, normals, colors, sources, use_dynamic=True, sequential_literal=False, sky=None):
     """oracle fusion: mode 0 = the snapshot formulation the GPU implements, mode 1 = the
     reference's literal sequential order (measurement only)"""
     fusion = importlib.import_module("mp-mvs_amd.fusion")
@@ -75,4 +75,20 @@ def fuse(cams, estimate, depths, normals, grays, sources, use_dynamic=True, sequ
     fn = l.orc_fuse
     fn.restype = C.c_int
     fn.argtypes = [C.c_int] + fusion.FUSE_ARGTYPES_TAIL
-    return fusion.call_fuse(fn, (1 if sequential_literal else 0,), cams, estimate, depths, normals, grays, sources, use_dynamic)
+    return fusion.call_fuse(fn, (1 if sequential_literal else 0,), cams, estimate, depths, normals, colors, sources, use_dynamic, sky)
+
+
+def sky_bilateral(bgr, mask, literal=False):
+    """oracle of mpmvs_sky_bilateral (mode 0) or the reference's literal arithmetic (mode 1, measurement only)"""
+    import numpy as np
+    l, _ = lib()
+    fn = l.orc_sky_bilateral
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    mask = np.ascontiguousarray(mask, np.float32)
+    assert bgr.shape == mask.shape + (3,)
+    out = np.empty(mask.shape, np.float32)
+    if fn(1 if literal else 0, bgr.ctypes.data, mask.ctypes.data, out.ctypes.data, mask.shape[0], mask.shape[1]) != 0:
+        raise RuntimeError("orc_sky_bilateral failed")
+    return out

@@ -101,10 +101,19 @@ struct Views {
     const int* estimate;
     const float* const* depths;
     const float* const* normals;
-    const float* const* gray;
+    const unsigned char* const* colors;
+    int cch;
     const int* src_off;
     const int* src_ids;
 };
+
+inline void load_color(const Views& V, int k, size_t idx, float c[3]) {
+    if (V.cch == 3) {
+        for (int q = 0; q < 3; ++q) c[q] = (float)V.colors[k][idx * 3 + q];
+    } else {
+        c[0] = c[1] = c[2] = (float)V.colors[k][idx];
+    }
+}
 
 // one pixel of image i against the masks `M`; returns true and fills out9 / used[]
 // (source pixel index per neighbour slot or -1) when a point is produced
@@ -118,8 +127,8 @@ inline bool fuse_pixel(const Views& V, int i, int r, int c, unsigned char* const
     float PX[3];
     point_on_world(rc, c, r, ref_depth, PX);
     float sp[3] = {PX[0], PX[1], PX[2]}, sn[3] = {rn[0], rn[1], rn[2]};
-    const float g0 = V.gray[i][(size_t)r * cols + c];
-    float scol[3] = {g0, g0, g0};
+    float scol[3];
+    load_color(V, i, (size_t)r * cols + c, scol);
     int num = 0;
     float dyn = 0.0f;
     const int b = V.src_off[i], num_ngb = V.src_off[i + 1] - b;
@@ -157,10 +166,11 @@ inline bool fuse_pixel(const Views& V, int i, int r, int c, unsigned char* const
             sn[0] += snrm[0];
             sn[1] += snrm[1];
             sn[2] += snrm[2];
-            const float gs = V.gray[s][sidx];
-            scol[0] += gs;
-            scol[1] += gs;
-            scol[2] += gs;
+            float gs[3];
+            load_color(V, s, sidx, gs);
+            scol[0] += gs[0];
+            scol[1] += gs[1];
+            scol[2] += gs[2];
             const float idx = (err + 200.0f * rel) + angle * 10.0f;
             dyn += LITERAL ? (float)std::exp(-(double)idx) : det_exp(-idx);
             num++;
@@ -180,10 +190,11 @@ inline bool fuse_pixel(const Views& V, int i, int r, int c, unsigned char* const
 }  // namespace
 
 extern "C" int orc_fuse(int mode, int n, const void* cams_, const int* estimate, const float* const* depths, const float* const* normals,
-                        const float* const* gray, const int* src_off, const int* src_ids, int use_dynamic, unsigned char* const* out_valid,
-                        float* const* out_points9, unsigned char* const* masks) {
+                        const unsigned char* const* colors, int color_channels, const unsigned char* const* sky, const int* src_off,
+                        const int* src_ids, int use_dynamic, unsigned char* const* out_valid, float* const* out_points9,
+                        unsigned char* const* masks) {
     const Camera* cams = (const Camera*)cams_;
-    Views V{n, cams, estimate, depths, normals, gray, src_off, src_ids};
+    Views V{n, cams, estimate, depths, normals, colors, color_channels, src_off, src_ids};
     for (int i = 0; i < n; ++i) {
         const size_t wh = (size_t)cams[i].width * cams[i].height;
         std::memset(masks[i], 0, wh);
@@ -201,6 +212,10 @@ extern "C" int orc_fuse(int mode, int n, const void* cams_, const int* estimate,
             for (int r = 0; r < rows; ++r)
                 for (int c = 0; c < cols; ++c) {
                     if (masks[i][(size_t)r * cols + c] == 1) continue;
+                    if (sky && sky[i] && sky[i][(size_t)r * cols + c] > 0) {  // ref :385-388
+                        masks[i][(size_t)r * cols + c] = 1;
+                        continue;
+                    }
                     float o[9];
                     if (fuse_pixel<true>(V, i, r, c, masks, use_dynamic, o, used)) {
                         out_valid[i][(size_t)r * cols + c] = 1;
@@ -229,6 +244,10 @@ extern "C" int orc_fuse(int mode, int n, const void* cams_, const int* estimate,
             for (int r = 0; r < rows; ++r)
                 for (int c = 0; c < cols; ++c) {
                     if (masks[i][(size_t)r * cols + c] == 1) continue;
+                    if (sky && sky[i] && sky[i][(size_t)r * cols + c] > 0) {  // own pixel: read by this iteration only
+                        masks[i][(size_t)r * cols + c] = 1;
+                        continue;
+                    }
                     for (int j = 0; j < num_ngb; ++j) used[j] = -1;
                     float o[9];
                     if (fuse_pixel<false>(V, i, r, c, masks, use_dynamic, o, used)) {
@@ -244,5 +263,46 @@ extern "C" int orc_fuse(int mode, int n, const void* cams_, const int* estimate,
             std::memcpy(masks[s], next[s].data(), next[s].size());
         }
     }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// sky-mask joint-bilateral filter (reference SkySegment/src/SkyRegionDetect.cu:3-34;
+// SURVEY.md row f-4).  mode 0: canonical arithmetic, what the HIP kernel computes
+// (mp-mvs_amd/csrc/pm_sky.hpp); mode 1: literal -- libm expf, separate multiply and add,
+// out-of-image taps skipped -- to measure the deviation.
+// ---------------------------------------------------------------------------------------
+extern "C" int orc_sky_bilateral(int mode, const unsigned char* bgr, const float* mask, float* out, int height, int width) {
+    const int half = 18;
+    std::vector<float> spatial((2 * half + 1) * (2 * half + 1));
+    for (int i = -half; i <= half; ++i)
+        for (int j = -half; j <= half; ++j) spatial[(i + half) * (2 * half + 1) + (j + half)] = -(sqrtf((float)(i * i + j * j)) / 72.0f);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+            const size_t idx = (size_t)y * width + x;
+            const float cb = (float)bgr[3 * idx], cg = (float)bgr[3 * idx + 1], cr = (float)bgr[3 * idx + 2];
+            float wsum = 0.0f, prob = 0.0f;
+            for (int i = -half; i <= half; ++i)
+                for (int j = -half; j <= half; ++j) {
+                    const int nx = x + i, ny = y + j;
+                    if (nx < 0 || nx >= width || ny < 0 || ny >= height) continue;
+                    const size_t k = (size_t)ny * width + nx;
+                    const float db = (float)bgr[3 * k] - cb, dg = (float)bgr[3 * k + 1] - cg, dr = (float)bgr[3 * k + 2] - cr;
+                    const float dc = sqrtf((db * db + dg * dg) + dr * dr);
+                    const float sp = spatial[(i + half) * (2 * half + 1) + (j + half)];
+                    if (mode == 1) {
+                        const float w = expf(sp - dc / 8.0f);
+                        wsum += w;
+                        const float p = w * mask[k];
+                        prob += p;
+                    } else {
+                        const float w = det_exp(fmaf(dc, -0.125f, sp));
+                        wsum += w;
+                        prob = fmaf(w, mask[k], prob);
+                    }
+                }
+            out[idx] = (double)(prob / wsum) > 0.6 ? 255.0f : 0.0f;
+        }
     return 0;
 }

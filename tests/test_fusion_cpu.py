@@ -68,3 +68,43 @@ def test_snapshot_vs_reference_sequential_order(pm, oracle):
     assert abs(np.median(z0) - np.median(z1)) < 2e-3
     agree = (v0[0] == v1[0]).mean()
     assert agree > 0.97
+
+
+def _colours_and_sky(grays, seed=3):
+    """B,G,R images derived from the grey ones and a sky mask per image (top rows + scattered pixels)"""
+    rng = np.random.default_rng(seed)
+    cols = [np.stack([g, 255 - g, (g * 0.5 + 20)], -1).round().astype(np.uint8) for g in grays]
+    sky = []
+    for k, g in enumerate(grays):
+        m = np.zeros(g.shape, np.uint8)
+        m[: 6 + 2 * k] = 255
+        m[rng.random(g.shape) < 0.02] = 1            # any value > 0 counts (reference :385)
+        sky.append(m)
+    sky[2] = None                                     # an image without a mask
+    return cols, sky
+
+
+def test_colour_and_sky_mask(pm, oracle):
+    """colour = mean of the B,G,R values of the consistent pixels (reference :394,:448-450,:466-468); a sky pixel is masked when
+    ITS image is fused (:385-388): it produces no point and is no longer available to later images, but earlier images
+    may still have used it"""
+    sc, cams, depths, normals, grays, neigh = _scene(pm)
+    cols, sky = _colours_and_sky(grays)
+    cloud_g, valid_g, _ = oracle.fuse(cams, [True] * 6, depths, normals, grays, neigh)
+    cloud_c, valid_c, _ = oracle.fuse(cams, [True] * 6, depths, normals, cols, neigh)
+    assert all(np.array_equal(a, b) for a, b in zip(valid_g, valid_c)) and np.array_equal(cloud_g[:, :6], cloud_c[:, :6])
+    assert np.allclose(cloud_c[:, 6], cloud_g[:, 6], atol=1e-3)                        # channel 0 is the grey image itself
+    assert np.allclose(cloud_c[:, 7], 255 - cloud_g[:, 6], atol=1e-2)                  # averaging is linear
+    cloud_s, valid_s, masks_s = oracle.fuse(cams, [True] * 6, depths, normals, cols, neigh, sky=sky)
+    for k in range(6):
+        if sky[k] is None:
+            continue
+        on = sky[k] > 0
+        assert valid_s[k][on].sum() == 0 and masks_s[k][on].all()
+    assert np.array_equal(valid_s[0][sky[0] == 0], valid_c[0][sky[0] == 0])            # image 0 sees no mask but its own sky
+    assert len(cloud_s) < len(cloud_c)
+    # literal sequential order agrees on sky handling
+    _, valid_l, masks_l = oracle.fuse(cams, [True] * 6, depths, normals, cols, neigh, sky=sky, sequential_literal=True)
+    for k in range(6):
+        if sky[k] is not None:
+            assert valid_l[k][sky[k] > 0].sum() == 0 and masks_l[k][sky[k] > 0].all()

@@ -4,7 +4,7 @@ import importlib
 import numpy as np
 import pytest
 
-from test_fusion_cpu import _scene
+from test_fusion_cpu import _colours_and_sky, _scene
 
 pytestmark = pytest.mark.gpu
 
@@ -23,6 +23,19 @@ def test_fusion_bit_exact(pm, oracle, engine, use_dynamic):
         assert np.array_equal(a, b)
     for a, b in zip(mg, mc):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("use_sky", [False, True])
+def test_fusion_colour_and_sky_bit_exact(pm, oracle, engine, use_sky):
+    fusion = importlib.import_module("mp-mvs_amd.fusion")
+    sc, cams, depths, normals, grays, neigh = _scene(pm, size=(128, 96))
+    cols, sky = _colours_and_sky(grays)
+    sky = sky if use_sky else None
+    cg, vg, mg = fusion.fuse(cams, [True] * 6, depths, normals, cols, neigh, sky=sky)
+    cc, vc, mc = oracle.fuse(cams, [True] * 6, depths, normals, cols, neigh, sky=sky)
+    assert len(cg) > 1000 and np.array_equal(cg, cc)
+    assert all(np.array_equal(a, b) for a, b in zip(vg, vc)) and all(np.array_equal(a, b) for a, b in zip(mg, mc))
+    assert np.ptp(cg[:, 6] - cg[:, 7]) > 10        # three distinct channels came through
 
 
 def test_fusion_of_estimated_maps(pm, oracle, engine):

@@ -193,6 +193,70 @@ def test_camera_pair_and_image_files(pm, hostlib, tmp_path):
     assert lst[1][2] == [1] + [s for k, s in enumerate(neigh[1][:3]) if k != 2]
 
 
+def _test_picture(w, h, seed=0):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([127 + 100 * np.sin(xx / 7.0) * np.cos(yy / 5.0), 127 + 80 * np.cos(xx / 13.0 + yy / 9.0), (xx * 3 + yy * 2) % 256], -1)
+    return np.clip(img + rng.normal(0, 12, (h, w, 3)), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("size", [(1, 1), (3, 2), (17, 9), (67, 53), (200, 152)])
+@pytest.mark.parametrize("options", [dict(quality=90, subsampling=0), dict(quality=90, subsampling=1), dict(quality=75, subsampling=2),
+                                     dict(quality=30, subsampling=2, progressive=True), dict(quality=95, subsampling=0, progressive=True, optimize=True),
+                                     dict(quality=85, subsampling=2, restart_marker_blocks=3), dict(quality=85, subsampling="4:1:1"),
+                                     dict(quality=80, grey=True), dict(quality=80, grey=True, progressive=True)])
+def test_jpeg_decoder_equals_libjpeg(hostlib, size, options):
+    """Image ingest: the own JPEG decoder returns exactly the pixels libjpeg(-turbo) -- i.e.
+    cv::imread, reference src/PatchMatch.cpp:877 (GRAYSCALE = the luminance plane) and :324 (COLOR = B,G,R) --
+    returns, for baseline, progressive, restart-interval and subsampled files.  PIL is the libjpeg front end."""
+    import io
+    Image = pytest.importorskip("PIL.Image")
+    w, h = size
+    options = dict(options)
+    grey = options.pop("grey", False)
+    pic = _test_picture(w, h)
+    buf = io.BytesIO()
+    Image.fromarray(pic[..., 0] if grey else pic).save(buf, "JPEG", **options)
+    data = buf.getvalue()
+    lum = Image.open(io.BytesIO(data))
+    lum.draft("L", (w, h))                      # libjpeg out_color_space = JCS_GRAYSCALE, what OpenCV requests
+    lum = np.asarray(lum)
+    rgb = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+    assert np.array_equal(hostlib.decode_jpeg(data, 1), lum)
+    assert np.array_equal(hostlib.decode_jpeg(data, 3)[..., ::-1], rgb)
+
+
+def test_jpeg_decoder_rejects_bad_input(hostlib):
+    import io
+    Image = pytest.importorskip("PIL.Image")
+    for junk in (b"", b"\xff\xd8", b"P5\n1 1\n255\n\x00", b"\xff\xd8\xff\xd9"):
+        with pytest.raises(RuntimeError):
+            hostlib.decode_jpeg(junk, 1)
+    buf = io.BytesIO()
+    Image.fromarray(_test_picture(200, 150)).save(buf, "JPEG", quality=90)
+    data = buf.getvalue()
+    assert hostlib.decode_jpeg(data[: 2 * len(data) // 3], 1).shape == (150, 200)      # truncated data decodes (zero bits), as libjpeg does
+    cmyk = io.BytesIO()
+    Image.fromarray(np.zeros((8, 8, 4), np.uint8), "CMYK").save(cmyk, "JPEG")
+    with pytest.raises(RuntimeError):
+        hostlib.decode_jpeg(cmyk.getvalue(), 1)                                     # 4 components: unsupported, loudly
+
+
+def test_image_files_by_content(hostlib, tmp_path):
+    """readGrayImage / readColorImage pick the format by content: JPEG, PGM, PPM (PPM -> grey with OpenCV's BGR2GRAY weights)"""
+    pic = _test_picture(33, 21)
+    open(tmp_path / "a.ppm", "wb").write(b"P6\n# comment\n33 21\n255\n" + pic.tobytes())
+    open(tmp_path / "a.pgm", "wb").write(b"P5 33 21 255\n" + pic[..., 1].tobytes())
+    assert np.array_equal(hostlib.read_image(tmp_path / "a.ppm", 3), pic[..., ::-1])
+    r, g, b = (pic[..., k].astype(np.int64) for k in range(3))
+    assert np.array_equal(hostlib.read_image(tmp_path / "a.ppm", 1), ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8))
+    assert np.array_equal(hostlib.read_image(tmp_path / "a.pgm", 1), pic[..., 1])
+    assert np.array_equal(hostlib.read_image(tmp_path / "a.pgm", 3), pic[..., 1:2].repeat(3, -1))
+    assert np.array_equal(hostlib.read_pgm(tmp_path / "a.pgm"), pic[..., 1].astype(np.float32))
+    with pytest.raises(RuntimeError):
+        hostlib.read_image(tmp_path / "missing.jpg", 1)
+
+
 def test_resize_linear_geometry(hostlib):
     """INTER_LINEAR geometry (reference src/PatchMatch.cpp:915): a linear ramp stays the same
     ramp under resampling (sampled at (x+0.5)*scale-0.5), constants stay constant, 2x
