@@ -80,6 +80,33 @@ PM_DEV float d_rcp(float z) {
     return __uint_as_float(__float_as_uint(r) | (zi & 0x80000000u));
 }
 
+// d_exp for arguments known to lie in [-80, 80] (no NaN): the same value, without the range tests
+PM_DEV float d_exp_inrange(float x) {
+    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    const float y = __builtin_fmaf(p, r * r, r) + 1.0f;
+    return __uint_as_float(__float_as_uint(y) + ((uint32_t)(int)n << 23));
+}
+
+// correctly rounded sqrt for x = 0 or normal x well inside the exponent range (no scaling, no inf/NaN
+// handling): the hardware estimate is within 1 ulp; the residuals of its two neighbours decide
+PM_DEV float d_sqrt_normal(float x) {
+    float s;
+    asm("v_sqrt_f32 %0, %1" : "=v"(s) : "v"(x));
+    const float lo = __uint_as_float(__float_as_uint(s) - 1u), hi = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_lo = __builtin_fmaf(-lo, s, x), r_hi = __builtin_fmaf(-hi, s, x);
+    s = r_lo <= 0.0f ? lo : s;
+    s = r_hi > 0.0f ? hi : s;
+    return s;
+}
+
 PM_DEV float d_exp(float x) {
     if (x < -80.0f) return 0.0f;
     if (x > 80.0f) return __uint_as_float(0x7f800000u);

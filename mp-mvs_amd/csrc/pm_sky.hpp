@@ -27,9 +27,9 @@ constexpr int kSkyLW = kSkyTW + 2 * kSkyHalf, kSkyLH = kSkyTH + 2 * kSkyHalf;
 PM_DEV void sky_tap(uint2 t, float cb, float cg, float cr, float sp, float& wsum, float& prob) {
     const float db = ubyte_to_float<0>(t.x) - cb, dg = ubyte_to_float<1>(t.x) - cg, dr = ubyte_to_float<2>(t.x) - cr;
     const float d2 = (db * db + dg * dg) + dr * dr;  // integers below 2^24: exact in any order
-    const float dc = __builtin_sqrtf(d2);
+    const float dc = d_sqrt_normal(d2);  // 0 or an integer below 2^18
     const float e = __builtin_fmaf(dc, -0.125f, sp);  // -distance/72 - dis_color/8; the product is exact
-    float w = d_exp(e);
+    float w = d_exp_inrange(e);  // e in [-56, 0]
     w = (t.x >> 24) ? w : 0.0f;
     wsum += w;
     prob = __builtin_fmaf(w, __uint_as_float(t.y), prob);
