@@ -536,7 +536,7 @@ int mpmvs_host_read_pgm(const char* path, float* data, size_t capacity_floats, i
 // <folder>/MPMVS/MPMVS_model.ply; returns the number of points or -1
 long mpmvs_host_fuse_folder(const char* input_folder, int device, int max_src, int use_dynamic_consistency, int sky_seg) {
     std::vector<Scene> Scenes;
-    GenerateSampleList(input_folder, max_src, 3200, Scenes);
+    GenerateSampleList(input_folder, max_src, 3200, Scenes);  // RunFusion does not use the image-size limit
     const std::string in = input_folder;
     return RunFusion(in, in + "/MPMVS", Scenes, use_dynamic_consistency != 0, device, sky_seg != 0);
 }
@@ -565,9 +565,9 @@ int mpmvs_host_decode_jpeg(const unsigned char* bytes, size_t size, int channels
     return 0;
 }
 int mpmvs_host_run_folder(const char* input_folder, int device, int max_src, int geom_iterations, int planar_prior,
-                          int geomPlanarPrior, int max_scale, uint64_t seed) {
+                          int geomPlanarPrior, int max_scale, uint64_t seed, int max_image_size) {
     std::vector<Scene> Scenes;
-    GenerateSampleList(input_folder, max_src, 3200, Scenes);
+    GenerateSampleList(input_folder, max_src, max_image_size > 0 ? max_image_size : 3200, Scenes);
     const std::string in = input_folder, out = in + "/MPMVS";
     mkdir(out.c_str(), 0777);
     bool pp = !geomPlanarPrior && planar_prior;

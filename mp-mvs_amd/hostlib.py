@@ -43,7 +43,7 @@ def load():
         lib.mpmvs_host_read_pgm.restype = C.c_int
         lib.mpmvs_host_read_pgm.argtypes = [C.c_char_p, P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.mpmvs_host_run_folder.restype = C.c_int
-        lib.mpmvs_host_run_folder.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]
+        lib.mpmvs_host_run_folder.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int]
         lib.mpmvs_host_fuse_folder.restype = C.c_long
         lib.mpmvs_host_fuse_folder.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
         lib.mpmvs_host_refine_sky_masks.restype = C.c_int
@@ -189,9 +189,10 @@ def decode_jpeg(data, channels=1):
     return out
 
 
-def run_folder(folder, device=0, max_src=20, geom_iterations=2, planar_prior=True, geom_planar_prior=True, max_scale=2, seed=12345):
+def run_folder(folder, device=0, max_src=20, geom_iterations=2, planar_prior=True, geom_planar_prior=True, max_scale=2, seed=12345,
+               max_image_size=3200):
     rc = load().mpmvs_host_run_folder(str(folder).encode(), device, max_src, geom_iterations, 1 if planar_prior else 0,
-                                      1 if geom_planar_prior else 0, max_scale, seed)
+                                      1 if geom_planar_prior else 0, max_scale, seed, max_image_size)
     if rc != 0:
         raise RuntimeError(f"run_folder failed ({rc})")
 

@@ -166,3 +166,40 @@ def test_end_to_end_scene_tool(pm, engine, tmp_path):
     assert rep["depth_within_1pct_of_gt"] > 0.7
     raw = open(ply, "rb").read()
     assert raw.startswith(b"ply\n") and len(raw.split(b"end_header\n", 1)[1]) == rep["fused_points"] * 27
+
+
+def test_config_driven_main_flow(pm, engine, tmp_path):
+    """tools/mpmvs_main.py = the reference's main() (src/main.cpp:6-55) with its config.yaml keys: JPEG images in,
+    depth-map passes, sky-mask refinement, fusion, PLY out"""
+    import json
+    import os
+    import subprocess
+    import sys
+    hostlib = importlib.import_module("mp-mvs_amd.hostlib")
+    sc, neigh = pm.synth.make_grid_scene(160, 120, 3, 2, spacing=0.4, rot_deg=1.0, quantize=True)
+    cams = [v.cam for v in sc.views]
+    cols = [np.stack([g, 255 - g, g // 2 + 20], -1).astype(np.uint8) for g in (np.asarray(v.image).astype(np.uint8) for v in sc.views)]
+    hostlib.write_dataset(str(tmp_path), cams, cols, neigh, fmt="jpg", jpeg_options=dict(quality=97, subsampling=0))
+    for i in range(6):
+        d = tmp_path / "MPMVS" / f"2333_{i:08d}"
+        d.mkdir(parents=True)
+        m = np.zeros((120, 160), np.uint8)
+        m[:12] = 255
+        open(d / "skymask.pgm", "wb").write(b"P5\n160 120\n255\n" + m.tobytes())
+    cfg = tmp_path / "config.yaml"
+    cfg.write_text(f'%YAML:1.0\n---\nInput-folder: "{tmp_path}"\nOutput-folder: "{tmp_path}"\nGeometric consistency iterations: 1\nPlaner prior: 1\n'
+                   'Geometric consistency planer prior: 0\nSky segment: 1\nUse dynamic_consistency to fuse: 1\nSave Dmb as JPG: 1\n'
+                   'Max source images num: 20\nMax image size: 3200\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "mpmvs_main.py"), "--config", str(cfg), "--seed", "7"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rep["sky_masks"] == 6 and rep["fused_points"] > 1000
+    body = open(rep["ply"], "rb").read().split(b"end_header\n", 1)[1]
+    assert len(body) == rep["fused_points"] * 27
+    xyz = np.frombuffer(body, np.uint8).reshape(-1, 27)[:, :12].copy().view(np.float32)
+    err = np.abs(xyz[:, 2] - pm.synth.height_field(xyz[:, 0].astype(np.float64), xyz[:, 1].astype(np.float64)))
+    assert np.median(err) < 0.05
+    for i in range(6):
+        assert (tmp_path / "MPMVS" / f"2333_{i:08d}" / "skymask_refine.pgm").exists() and (tmp_path / "MPMVS" / f"2333_{i:08d}" / "depths.dmb").exists()
