@@ -55,6 +55,16 @@ def set_num_threads(n):
     lib()[0].orc_set_num_threads(int(n))
 
 
+def set_literal_mode(handle, mode):
+    """0: canonical NCC (default); 1: every NCC evaluation of run()/step() in the reference's literal operation order with libm;
+    2: additionally CUDA's 8-bit texture interpolation fractions.  Measurement only (end-to-end statistics)."""
+    l, _ = lib()
+    l.orc_set_literal_mode.restype = C.c_int
+    l.orc_set_literal_mode.argtypes = [C.c_void_p, C.c_int]
+    if l.orc_set_literal_mode(handle._ctx, int(mode)) != 0:
+        raise RuntimeError("orc_set_literal_mode failed")
+
+
 def eval_ncc_literal(handle, params, planes_cam, scale, quantize_fraction=False):
     """NCC in the reference's literal operation order (see pm_oracle.cpp); measurement only"""
     import numpy as np

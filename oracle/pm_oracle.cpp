@@ -246,6 +246,7 @@ struct Ctx {
     std::vector<F4> prior;
     std::vector<uint32_t> mask;
     bool have_prior = false;
+    int literal_mode = 0;  // 0 canonical NCC; 1 literal restatement; 2 literal + 8-bit texture fractions (measurement only)
     std::string err;
 };
 
@@ -377,6 +378,15 @@ inline F4 perturbed_normal(const Camera& cam, int px, int py, const F4& normal, 
 // reference moments depend only on the reference image, so they are computed
 // once per pixel and scale (ref .cu:318-323, :363-395 reference-image terms).
 // ---------------------------------------------------------------------------
+// Measurement hook: with Ctx::literal_mode != 0 every NCC evaluation of the schedule is computed by literal_ncc
+// (below) instead of the canonical formulation, to compare end-to-end statistics (tests/test_oracle_cpu.py).  The
+// literal form needs the plane, scale and parameters, which the canonical call sites pass on through m / RefWin:
+// plane_to_m and ref_window (always called right before the evaluations they serve) leave them here.
+static thread_local F4 tl_plane;
+static thread_local int tl_scale = 0;
+static thread_local const Params* tl_prm = nullptr;
+float literal_ncc(const Ctx& c, const Params& prm, int px, int py, const F4& pl, int v, int scale, int quantize);
+
 struct RefWin {
     float w[36];
     float wr[36];
@@ -387,6 +397,8 @@ struct RefWin {
 };
 
 inline void ref_window(const Ctx& c, const Params& prm, int px, int py, int scale, RefWin& rw) {
+    tl_scale = scale;
+    tl_prm = &prm;
     const Image& ref = c.imgs[0];
     const int step = 2 << scale;          // ref .cu:342-345
     const int radius = 5 * step / 2;      // ref .cu:346
@@ -440,6 +452,7 @@ inline float bilinear(const Image& im, float sx, float sy) {
 
 // plane -> m = (n^T K_r^-1) / d   (per hypothesis, shared by all views)
 inline void plane_to_m(const Ctx& c, const F4& pl, float m[3]) {
+    tl_plane = pl;
     const float inv_d = 1.0f / pl.w;
     m[0] = (pl.x * c.ifx) * inv_d;
     m[1] = (pl.y * c.ify) * inv_d;
@@ -448,6 +461,7 @@ inline void plane_to_m(const Ctx& c, const F4& pl, float m[3]) {
 
 // ref .cu:325-414 ComputeBilateralNCC for one (plane, source view)
 inline float ncc_cost(const Ctx& c, const RefWin& rw, int px, int py, const float m[3], int v /*0-based source*/) {
+    if (c.literal_mode) return literal_ncc(c, *tl_prm, px, py, tl_plane, v, tl_scale, c.literal_mode == 2);
     const ViewConst& vc = c.vc[v];
     const Image& src = c.imgs[v + 1];
     float Hm[9];
@@ -1068,6 +1082,94 @@ int run(Ctx& c, const Params& prm, uint64_t seed) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Literal-arithmetic NCC: the reference's formulas in the reference's operation
+// order -- homography assembled per evaluation with its divisions (ref .cu:228-279),
+// one perspective division per tap (:281-288), libm expf/sqrtf for the bilateral
+// weight (:318-323), weighted sums accumulated row by row (:365-395), no hoisting
+// of the reference-window terms -- and, with quantize_fraction != 0, CUDA's texture
+// filtering with 8-bit interpolation fractions.  It exists only to MEASURE how far
+// the canonical arithmetic of DESIGN.md section 3 is from a literal transcription
+// (tests/test_oracle_cpu.py::test_canonical_vs_literal_arithmetic); nothing else uses it.
+// ---------------------------------------------------------------------------
+float literal_tex(const Image& im, float x, float y, int quantize) {
+    // tex2D(t, x + 0.5, y + 0.5), linear filter, clamp addressing
+    const float xb = x, yb = y;
+    const float fx = floorf(xb), fy = floorf(yb);
+    float ax = xb - fx, ay = yb - fy;
+    if (quantize) {
+        ax = floorf(ax * 256.0f + 0.5f) / 256.0f;
+        ay = floorf(ay * 256.0f + 0.5f) / 256.0f;
+    }
+    const int ix = (int)fx, iy = (int)fy;
+    const float t00 = im.at(ix, iy), t10 = im.at(ix + 1, iy), t01 = im.at(ix, iy + 1), t11 = im.at(ix + 1, iy + 1);
+    return (1.0f - ax) * (1.0f - ay) * t00 + ax * (1.0f - ay) * t10 + (1.0f - ax) * ay * t01 + ax * ay * t11;
+}
+
+float literal_ncc(const Ctx& c, const Params& prm, int px, int py, const F4& pl, int v, int scale, int quantize) {
+    const Camera& rc = c.cams[0];
+    const Camera& sc = c.cams[v + 1];
+    // R_rel = R_s R_r^T, t_rel = R_s (C_r - C_s)
+    float Rr[9], tr[3], Cd[3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Rr[i * 3 + j] = sc.R[i * 3] * rc.R[j * 3] + sc.R[i * 3 + 1] * rc.R[j * 3 + 1] + sc.R[i * 3 + 2] * rc.R[j * 3 + 2];
+    for (int k = 0; k < 3; ++k) Cd[k] = rc.C[k] - sc.C[k];
+    for (int i = 0; i < 3; ++i) tr[i] = sc.R[i * 3] * Cd[0] + sc.R[i * 3 + 1] * Cd[1] + sc.R[i * 3 + 2] * Cd[2];
+    float Hm[9], T[9];
+    const float n3[3] = {pl.x, pl.y, pl.z};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Hm[i * 3 + j] = Rr[i * 3 + j] - tr[i] * n3[j] / pl.w;
+    for (int i = 0; i < 3; ++i) {
+        T[i * 3 + 0] = Hm[i * 3 + 0] / rc.K[0];
+        T[i * 3 + 1] = Hm[i * 3 + 1] / rc.K[4];
+        T[i * 3 + 2] = -Hm[i * 3 + 0] * rc.K[2] / rc.K[0] - Hm[i * 3 + 1] * rc.K[5] / rc.K[4] + Hm[i * 3 + 2];
+    }
+    for (int j = 0; j < 3; ++j) {
+        Hm[0 + j] = sc.K[0] * T[0 + j] + sc.K[2] * T[6 + j];
+        Hm[3 + j] = sc.K[4] * T[3 + j] + sc.K[5] * T[6 + j];
+        Hm[6 + j] = sc.K[8] * T[6 + j];
+    }
+    auto warp = [&](int x, int y, float& u, float& w) {
+        const float a = Hm[0] * x + Hm[1] * y + Hm[2], b = Hm[3] * x + Hm[4] * y + Hm[5], z = Hm[6] * x + Hm[7] * y + Hm[8];
+        u = a / z;
+        w = b / z;
+    };
+    float cu, cv;
+    warp(px, py, cu, cv);
+    if (cu >= sc.width || cu < 0.0f || cv >= sc.height || cv < 0.0f) return 2.0f;
+    int step = 2;
+    for (int i = 0; i < scale; ++i) step *= 2;
+    const int radius = 5 * step / 2;
+    const Image& ref = c.imgs[0];
+    const Image& src = c.imgs[v + 1];
+    const float centre = ref.at(px, py);
+    float s_r = 0, s_rr = 0, s_s = 0, s_ss = 0, s_rs = 0, s_w = 0;
+    for (int i = -radius; i < radius + 1; i += step) {
+        float r_r = 0, r_rr = 0, r_s = 0, r_ss = 0, r_rs = 0, r_w = 0;
+        for (int j = -radius; j < radius + 1; j += step) {
+            const float rp = ref.at(px + i, py + j);
+            float u, w2;
+            warp(px + i, py + j, u, w2);
+            const float sp = literal_tex(src, u, w2, quantize);
+            const float sd = sqrtf((float)i * (float)i + (float)j * (float)j);
+            const float wt = expf(-sd / (2.0f * prm.sigma_spatial * prm.sigma_spatial) - fabsf(rp - centre) / (2.0f * prm.sigma_color * prm.sigma_color));
+            r_r += wt * rp;
+            r_rr += wt * rp * rp;
+            r_s += wt * sp;
+            r_ss += wt * sp * sp;
+            r_rs += wt * rp * sp;
+            r_w += wt;
+        }
+        s_r += r_r; s_rr += r_rr; s_s += r_s; s_ss += r_ss; s_rs += r_rs; s_w += r_w;
+    }
+    const float inv = 1.0f / s_w;
+    s_r *= inv; s_rr *= inv; s_s *= inv; s_ss *= inv; s_rs *= inv;
+    const float var_r = s_rr - s_r * s_r, var_s = s_ss - s_s * s_s;
+    if (var_r < 1e-5f || var_s < 1e-5f) return 2.0f;
+    const float cov = s_rs - s_r * s_s;
+    return std::fmax(0.0f, std::fmin(2.0f, 1.0f - cov / sqrtf(var_r * var_s)));
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -1205,92 +1307,10 @@ int orc_eval_geom(orc_ctx* h, const void* params, const float* planes_cam4, floa
     return 0;
 }
 
-// ---------------------------------------------------------------------------
-// Literal-arithmetic NCC: the reference's formulas in the reference's operation
-// order -- homography assembled per evaluation with its divisions (ref .cu:228-279),
-// one perspective division per tap (:281-288), libm expf/sqrtf for the bilateral
-// weight (:318-323), weighted sums accumulated row by row (:365-395), no hoisting
-// of the reference-window terms -- and, with quantize_fraction != 0, CUDA's texture
-// filtering with 8-bit interpolation fractions.  It exists only to MEASURE how far
-// the canonical arithmetic of DESIGN.md section 3 is from a literal transcription
-// (tests/test_oracle_cpu.py::test_canonical_vs_literal_arithmetic); nothing else uses it.
-// ---------------------------------------------------------------------------
-static float literal_tex(const Image& im, float x, float y, int quantize) {
-    // tex2D(t, x + 0.5, y + 0.5), linear filter, clamp addressing
-    const float xb = x, yb = y;
-    const float fx = floorf(xb), fy = floorf(yb);
-    float ax = xb - fx, ay = yb - fy;
-    if (quantize) {
-        ax = floorf(ax * 256.0f + 0.5f) / 256.0f;
-        ay = floorf(ay * 256.0f + 0.5f) / 256.0f;
-    }
-    const int ix = (int)fx, iy = (int)fy;
-    const float t00 = im.at(ix, iy), t10 = im.at(ix + 1, iy), t01 = im.at(ix, iy + 1), t11 = im.at(ix + 1, iy + 1);
-    return (1.0f - ax) * (1.0f - ay) * t00 + ax * (1.0f - ay) * t10 + (1.0f - ax) * ay * t01 + ax * ay * t11;
-}
-
-static float literal_ncc(const Ctx& c, const Params& prm, int px, int py, const F4& pl, int v, int scale, int quantize) {
-    const Camera& rc = c.cams[0];
-    const Camera& sc = c.cams[v + 1];
-    // R_rel = R_s R_r^T, t_rel = R_s (C_r - C_s)
-    float Rr[9], tr[3], Cd[3];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) Rr[i * 3 + j] = sc.R[i * 3] * rc.R[j * 3] + sc.R[i * 3 + 1] * rc.R[j * 3 + 1] + sc.R[i * 3 + 2] * rc.R[j * 3 + 2];
-    for (int k = 0; k < 3; ++k) Cd[k] = rc.C[k] - sc.C[k];
-    for (int i = 0; i < 3; ++i) tr[i] = sc.R[i * 3] * Cd[0] + sc.R[i * 3 + 1] * Cd[1] + sc.R[i * 3 + 2] * Cd[2];
-    float Hm[9], T[9];
-    const float n3[3] = {pl.x, pl.y, pl.z};
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) Hm[i * 3 + j] = Rr[i * 3 + j] - tr[i] * n3[j] / pl.w;
-    for (int i = 0; i < 3; ++i) {
-        T[i * 3 + 0] = Hm[i * 3 + 0] / rc.K[0];
-        T[i * 3 + 1] = Hm[i * 3 + 1] / rc.K[4];
-        T[i * 3 + 2] = -Hm[i * 3 + 0] * rc.K[2] / rc.K[0] - Hm[i * 3 + 1] * rc.K[5] / rc.K[4] + Hm[i * 3 + 2];
-    }
-    for (int j = 0; j < 3; ++j) {
-        Hm[0 + j] = sc.K[0] * T[0 + j] + sc.K[2] * T[6 + j];
-        Hm[3 + j] = sc.K[4] * T[3 + j] + sc.K[5] * T[6 + j];
-        Hm[6 + j] = sc.K[8] * T[6 + j];
-    }
-    auto warp = [&](int x, int y, float& u, float& w) {
-        const float a = Hm[0] * x + Hm[1] * y + Hm[2], b = Hm[3] * x + Hm[4] * y + Hm[5], z = Hm[6] * x + Hm[7] * y + Hm[8];
-        u = a / z;
-        w = b / z;
-    };
-    float cu, cv;
-    warp(px, py, cu, cv);
-    if (cu >= sc.width || cu < 0.0f || cv >= sc.height || cv < 0.0f) return 2.0f;
-    int step = 2;
-    for (int i = 0; i < scale; ++i) step *= 2;
-    const int radius = 5 * step / 2;
-    const Image& ref = c.imgs[0];
-    const Image& src = c.imgs[v + 1];
-    const float centre = ref.at(px, py);
-    float s_r = 0, s_rr = 0, s_s = 0, s_ss = 0, s_rs = 0, s_w = 0;
-    for (int i = -radius; i < radius + 1; i += step) {
-        float r_r = 0, r_rr = 0, r_s = 0, r_ss = 0, r_rs = 0, r_w = 0;
-        for (int j = -radius; j < radius + 1; j += step) {
-            const float rp = ref.at(px + i, py + j);
-            float u, w2;
-            warp(px + i, py + j, u, w2);
-            const float sp = literal_tex(src, u, w2, quantize);
-            const float sd = sqrtf((float)i * (float)i + (float)j * (float)j);
-            const float wt = expf(-sd / (2.0f * prm.sigma_spatial * prm.sigma_spatial) - fabsf(rp - centre) / (2.0f * prm.sigma_color * prm.sigma_color));
-            r_r += wt * rp;
-            r_rr += wt * rp * rp;
-            r_s += wt * sp;
-            r_ss += wt * sp * sp;
-            r_rs += wt * rp * sp;
-            r_w += wt;
-        }
-        s_r += r_r; s_rr += r_rr; s_s += r_s; s_ss += r_ss; s_rs += r_rs; s_w += r_w;
-    }
-    const float inv = 1.0f / s_w;
-    s_r *= inv; s_rr *= inv; s_s *= inv; s_ss *= inv; s_rs *= inv;
-    const float var_r = s_rr - s_r * s_r, var_s = s_ss - s_s * s_s;
-    if (var_r < 1e-5f || var_s < 1e-5f) return 2.0f;
-    const float cov = s_rs - s_r * s_s;
-    return std::fmax(0.0f, std::fmin(2.0f, 1.0f - cov / sqrtf(var_r * var_s)));
+int orc_set_literal_mode(orc_ctx* h, int mode) {
+    if (!h || mode < 0 || mode > 2) return -1;
+    h->c.literal_mode = mode;
+    return 0;
 }
 
 int orc_eval_ncc_literal(orc_ctx* h, const void* params, const float* planes_cam4, int scale, int quantize_fraction, float* out) {

@@ -346,3 +346,34 @@ def test_canonical_vs_literal_arithmetic(pm, oracle):
     lit = oracle.eval_ncc_literal(h, prm, planes, 0)
     both = (q < 2.0) & (lit < 2.0)
     assert np.median(np.abs(q - lit)[both]) < 5e-3
+
+
+def test_end_to_end_statistics_canonical_vs_literal(pm, oracle):
+    """SURVEY 8c tier T3: the whole Run() schedule (random init, 2 window scales x 3 red/black iterations, view selection,
+    refinement, filter) with EVERY NCC evaluation in (a) the canonical arithmetic the HIP kernels implement, (b) the
+    reference's literal operation order with libm, (c) literal + CUDA's 8-bit texture fractions.  Individual decisions
+    differ (ties flip, then the random walks diverge), the statistics must not: accuracy against the analytic ground truth
+    within +-2 percentage points (seed-to-seed scatter is +-1), mean matching cost within 2 %."""
+    ob = oracle
+    sc = pm.synth.make_problem_scene(160, 120, 4, quantize=True)
+    cams, imgs = sc.problem(0, [1, 2, 3, 4])
+    gt = sc.views[0].gt_depth
+    dmin, dmax = pm.synth.kernel_depth_range(cams[0])
+    stats = {}
+    for mode in (0, 1, 2):
+        acc1, acc3, cost = [], [], []
+        for seed in (1, 2):
+            h = ob.create()
+            h.set_views(cams, imgs)
+            ob.set_literal_mode(h, mode)
+            h.run(pm.PatchMatchParams(num_images=5, depth_min=float(dmin), depth_max=float(dmax), max_scale=1), seed)
+            planes, costs = h.get()
+            rel = np.abs(planes[..., 3] - gt) / gt
+            acc1.append((rel < 0.01).mean())
+            acc3.append((rel < 0.03).mean())
+            cost.append(costs.mean())
+        stats[mode] = (np.mean(acc1), np.mean(acc3), np.mean(cost))
+    assert stats[0][1] > 0.8                                           # the schedule converges on this scene
+    for mode in (1, 2):
+        assert abs(stats[mode][0] - stats[0][0]) < 0.02 and abs(stats[mode][1] - stats[0][1]) < 0.02, stats
+        assert abs(stats[mode][2] / stats[0][2] - 1.0) < 0.02, stats
