@@ -18,6 +18,9 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <atomic>
+#include <thread>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/mpmvs.h"
@@ -187,19 +190,64 @@ static int upload_extended(mpmvs_ctx* c, const float* host, size_t pitch, int w,
     return 0;
 }
 
-// host image (integers 0..255) -> dense staging buffer -> quad-packed u8 texture
-static int upload_quads(mpmvs_ctx* c, const float* host, size_t pitch, int w, int h, uint32_t** out) {
-    float* d_raw = nullptr;
-    HIPCHK(c, hipMalloc(&d_raw, (size_t)w * h * 4));
-    HIPCHK(c, hipMemcpy2DAsync(d_raw, (size_t)w * 4, host, pitch, (size_t)w * 4, h, hipMemcpyHostToDevice, c->stream));
+// 8-bit host image -> (shared staging buffer) -> quad-packed u8 texture.  Stream ordered: the staging buffer may be
+// overwritten by the next view's copy once this pack kernel has been enqueued.
+static int upload_quads_u8(mpmvs_ctx* c, const unsigned char* host8, unsigned char* d_stage, int w, int h, uint32_t** out) {
+    HIPCHK(c, hipMemcpyAsync(d_stage, host8, (size_t)w * h, hipMemcpyHostToDevice, c->stream));
     uint32_t* d_q = nullptr;
     HIPCHK(c, hipMalloc(&d_q, (size_t)w * h * 4));
-    hipLaunchKernelGGL(k_pack_quads, dim3((w + 255) / 256, h), dim3(256), 0, c->stream, d_raw, w, h, d_q);
+    *out = d_q;  // owned by the context from here on (freed by free_views also on a later error)
+    hipLaunchKernelGGL(k_pack_quads_u8, dim3((w + 255) / 256, h), dim3(256), 0, c->stream, d_stage, w, h, d_q);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipFree(d_raw));
-    *out = d_q;
     return 0;
+}
+
+// Are all source images integers in [0, 255] (the reference's imread(GRAYSCALE) -> CV_32F path)?  Checked and converted to
+// 8 bit in one pass, rows dealt to a few host threads; out8[v-1] receives view v's bytes.  Returns false at the first
+// non-integer pixel (the fp32 texture format is used then).
+static bool convert_sources_u8(int n, const mpmvs_camera* cams, const float* const* images, const size_t* pitch_bytes,
+                               std::vector<std::vector<unsigned char>>& out8) {
+    out8.assign(n - 1, std::vector<unsigned char>());
+    long total_rows = 0;
+    for (int v = 1; v < n; ++v) {
+        out8[v - 1].resize((size_t)cams[v].width * cams[v].height);
+        total_rows += cams[v].height;
+    }
+    std::atomic<bool> exact(true);
+    std::atomic<long> next(0);
+    auto work = [&]() {
+        const long chunk = 64;
+        for (;;) {
+            const long r0 = next.fetch_add(chunk);
+            if (r0 >= total_rows || !exact.load(std::memory_order_relaxed)) return;
+            long v = 1, base = 0;
+            for (long k = r0; k < std::min(r0 + chunk, total_rows); ++k) {
+                while (k - base >= cams[v].height) base += cams[v++].height;
+                const int y = (int)(k - base), w = cams[v].width;
+                const size_t pitch = pitch_bytes ? pitch_bytes[v] : (size_t)w * 4;
+                const float* row = (const float*)((const char*)images[v] + (size_t)y * pitch);
+                unsigned char* o = out8[v - 1].data() + (size_t)y * w;
+                bool ok = true;
+                for (int x = 0; x < w; ++x) {
+                    const float f = row[x];
+                    const int q = (int)(f >= 0.0f && f <= 255.0f ? f : -1.0f);
+                    ok &= (float)q == f;
+                    o[x] = (unsigned char)q;
+                }
+                if (!ok) {
+                    exact.store(false, std::memory_order_relaxed);
+                    return;
+                }
+            }
+        }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nthreads = (int)std::max(1u, std::min(8u, hw ? hw : 1u));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread& t : pool) t.join();
+    return exact.load();
 }
 
 extern "C" {
@@ -272,30 +320,26 @@ int mpmvs_set_views(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* 
     }
     // 8-bit exact input (the reference's imread path, ref .cpp:877-882) takes the
     // quad-packed u8 texture format; anything else stays fp32
-    bool exact = true;
-    for (int v = 1; v < n && exact; ++v) {
-        const int w = cams[v].width, h = cams[v].height;
-        const size_t pitch = pitch_bytes ? pitch_bytes[v] : (size_t)w * 4;
-        for (int y = 0; y < h && exact; ++y) {
-            const float* row = (const float*)((const char*)images[v] + (size_t)y * pitch);
-            for (int x = 0; x < w; ++x) {
-                const float f = row[x];
-                if (!(f >= 0.0f && f <= 255.0f) || f != (float)(int)f) {
-                    exact = false;
-                    break;
-                }
-            }
-        }
-    }
-    if (c->force_f32) exact = false;
+    std::vector<std::vector<unsigned char>> src8;
+    bool exact = !c->force_f32 && convert_sources_u8(n, cams, images, pitch_bytes, src8);
     c->all_u8 = exact;
     if (exact) c->d_src8.assign(n - 1, nullptr); else c->d_src.assign(n - 1, nullptr);
+    unsigned char* d_stage = nullptr;
+    if (exact) {
+        size_t biggest = 0;
+        for (int v = 1; v < n; ++v) biggest = std::max(biggest, (size_t)cams[v].width * cams[v].height);
+        HIPCHK(c, hipMalloc(&d_stage, biggest));
+    }
     for (int v = 1; v < n; ++v) {
         const int w = cams[v].width, h = cams[v].height;
         const size_t pitch = pitch_bytes ? pitch_bytes[v] : (size_t)w * 4;
         ViewDev& o = c->hP.views[v - 1];
         if (exact) {
-            if ((rc = upload_quads(c, images[v], pitch, w, h, &c->d_src8[v - 1]))) return rc;
+            if ((rc = upload_quads_u8(c, src8[v - 1].data(), d_stage, w, h, &c->d_src8[v - 1]))) {
+                (void)hipStreamSynchronize(c->stream);
+                (void)hipFree(d_stage);
+                return rc;
+            }
             o.pitch8 = w;
             o.img8 = c->d_src8[v - 1];
         } else {
@@ -313,7 +357,9 @@ int mpmvs_set_views(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* 
     HIPCHK(c, hipMemsetAsync(c->S.costs, 0, wh * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->S.sel, 0, wh * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->S.geom, 0, wh * 4, c->stream));
-    return upload_problem(c);
+    rc = upload_problem(c);  // synchronises the stream: the staged 8-bit copies are complete
+    if (d_stage) (void)hipFree(d_stage);
+    return rc;
 }
 
 static int attach_depths(mpmvs_ctx* c, int n_src, const int* widths, const int* heights) {

@@ -573,13 +573,14 @@ __global__ void k_pad(const float* __restrict__ src, int w, int h, float* __rest
     dst[(long)y * pw + x] = src[(long)sy * w + sx];
 }
 
-// dense w x h image of integers in [0,255] -> quad-packed u8 texture (SrcTex8), w x h dwords
-__global__ void k_pack_quads(const float* __restrict__ src, int w, int h, uint32_t* __restrict__ dst) {
+// dense 8-bit w x h image -> quad-packed u8 texture (SrcTex8), w x h dwords; the host converts the fp32 input to 8 bit
+// while it checks that every pixel is an integer in [0, 255] (4x less PCIe traffic than staging fp32)
+__global__ void k_pack_quads_u8(const unsigned char* __restrict__ src, int w, int h, uint32_t* __restrict__ dst) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w || y >= h) return;
     const int x1 = x + 1 > w - 1 ? w - 1 : x + 1, y1 = y + 1 > h - 1 ? h - 1 : y + 1;
-    const uint32_t b0 = (uint32_t)src[(long)y * w + x], b1 = (uint32_t)src[(long)y * w + x1];
-    const uint32_t b2 = (uint32_t)src[(long)y1 * w + x], b3 = (uint32_t)src[(long)y1 * w + x1];
+    const uint32_t b0 = src[(long)y * w + x], b1 = src[(long)y * w + x1];
+    const uint32_t b2 = src[(long)y1 * w + x], b3 = src[(long)y1 * w + x1];
     dst[(long)y * w + x] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
 }
 

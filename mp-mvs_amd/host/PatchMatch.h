@@ -139,6 +139,7 @@ class PatchMatchCUDA {
     const Image& GetReferenceImage();
     const Camera& GetReferenceCamera() const { return cameras[0]; }
     float4 GetPlaneHypothesis(const int index);
+    const float4* GetPlaneHypotheses() const { return hostPlaneHypotheses.data(); }  // the whole hostPlaneHypotheses array (no per-pixel call)
     float GetCost(const int index);
     float GetGeomCost(const int index);
 

@@ -4,6 +4,7 @@
 // exit(EXIT_FAILURE) (reference src/PatchMatch.cpp:60-65); the C ABI underneath
 // never exits.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -72,6 +73,18 @@ void PatchMatchCUDA::SetFolder(const std::string& in, const std::string& out) {
 }
 
 // reference src/PatchMatch.cpp:863-958, minus file reading and rescaling
+// MPMVS_HOST_TIMING=1: wall time of every stage of ProcessProblem on stderr
+struct StageTimer {
+    const bool on = std::getenv("MPMVS_HOST_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[mpmvs_host] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 void PatchMatchCUDA::PatchMatchInit(std::vector<Scene>& Scenes, const int ID) {
     images.clear();
     depths.clear();
@@ -164,6 +177,7 @@ void PatchMatchCUDA::CudaMemInit(Scene& scene) {
             exit(0);
         }
         const int width = scene.depth.cols, height = scene.depth.rows;
+#pragma omp parallel for schedule(static)
         for (int row = 0; row < height; ++row)
             for (int col = 0; col < width; ++col) {
                 const size_t idx = (size_t)row * width + col;
@@ -177,15 +191,21 @@ void PatchMatchCUDA::CudaMemInit(Scene& scene) {
 // reference src/PatchMatch.cpp:978-996
 void PatchMatchCUDA::CudaPlanarPriorInitialization(const std::vector<float4>& PlaneParams, const Image& masks) {
     const int W = cameras[0].width, H = cameras[0].height;
-    hostPriorPlanes.assign((size_t)W * H, float4{0, 0, 0, 0});
-    hostPlaneMask.assign((size_t)W * H, 0u);
+    StageTimer tm;
+    hostPriorPlanes.resize((size_t)W * H);
+    hostPlaneMask.resize((size_t)W * H);
+    tm.lap("  prior: resize");
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < H; ++i)
         for (int j = 0; j < W; ++j) {
             const size_t idx = (size_t)i * W + j;
-            hostPlaneMask[idx] = (unsigned int)masks.at(i, j);
-            if (masks.at(i, j) > 0) hostPriorPlanes[idx] = PlaneParams[(size_t)masks.at(i, j) - 1];
+            const float m = masks.at(i, j);
+            hostPlaneMask[idx] = (unsigned int)m;
+            hostPriorPlanes[idx] = m > 0 ? PlaneParams[(size_t)m - 1] : float4{0, 0, 0, 0};
         }
+    tm.lap("  prior: expand");
     check(mpmvs_set_prior(ctx, hostPriorPlanes.data(), hostPlaneMask.data()), "mpmvs_set_prior");
+    tm.lap("  prior: mpmvs_set_prior");
 }
 
 // reference src/PatchMatch.cu:1188-1254: the launches live behind mpmvs_run, the
@@ -225,6 +245,10 @@ void PatchMatchCUDA::GetTriangulateVertices(std::vector<Point>& Vertices) {
 
 // reference src/PatchMatch.cpp:1091-1139
 void PatchMatchCUDA::Release(std::vector<Scene>&, const int&) {
+    StageTimer tm;
+    if (ctx) mpmvs_destroy(ctx);
+    ctx = nullptr;
+    tm.lap("  release: mpmvs_destroy");
     hostPlaneHypotheses.clear();
     hostCosts.clear();
     hostGeomCosts.clear();
@@ -235,18 +259,23 @@ void PatchMatchCUDA::Release(std::vector<Scene>&, const int&) {
 }
 
 // reference src/PatchMatch.cpp:506-638
+
 void ProcessProblem(std::vector<Scene>& Scenes, const int ID, bool geom_consistency, bool planar_prior, uint64_t seed,
                     int device, int max_scale, ProblemResult* results) {
     Scene& scene = Scenes[ID];
+    StageTimer tm;
     PatchMatchCUDA MP;
     MP.SetDevice(device);
     MP.SetSeed(seed);
     MP.SetMaxScale(max_scale);
     MP.SetGeomConsistencyParams(geom_consistency, planar_prior);
     MP.PatchMatchInit(Scenes, ID);
+    tm.lap("PatchMatchInit");
     MP.AllocatePatchMatch();
     MP.CudaMemInit(Scenes[ID]);
+    tm.lap("Allocate + CudaMemInit");
     MP.Run();
+    tm.lap("Run");
 
     const int width = MP.GetReferenceImageWidth();
     const int height = MP.GetReferenceImageHeight();
@@ -257,16 +286,19 @@ void ProcessProblem(std::vector<Scene>& Scenes, const int ID, bool geom_consiste
         const Rect imageRC{0, 0, width, height};
         std::vector<Point> Vertices;
         MP.GetTriangulateVertices(Vertices);
+        tm.lap("GetTriangulateVertices");
         const auto triangles = MP.DelaunayTriangulation(imageRC, Vertices);
+        tm.lap("DelaunayTriangulation");
         Image mask_tri;
         std::vector<float4> planeParams_tri;
-        std::vector<float4> planes((size_t)width * height);
-        for (size_t i = 0; i < planes.size(); ++i) planes[i] = MP.GetPlaneHypothesis((int)i);
-        mpmvs_host::BuildPrior(MP.GetReferenceCamera(), width, height, triangles, planes.data(), MP.GetMinDepth(), MP.GetMaxDepth(),
+        mpmvs_host::BuildPrior(MP.GetReferenceCamera(), width, height, triangles, MP.GetPlaneHypotheses(), MP.GetMinDepth(), MP.GetMaxDepth(),
                                planeParams_tri, mask_tri);
+        tm.lap("BuildPrior");
         MP.CudaPlanarPriorInitialization(planeParams_tri, mask_tri);
+        tm.lap("CudaPlanarPriorInit");
         MP.SetSeed(seed + 0x9E3779B97F4A7C15ull);  // second Run(): its own RNG streams
         MP.Run();
+        tm.lap("Run (prior)");
         MP.SetGeomConsistencyParams(geom_consistency, planar_prior);
     }
 
@@ -275,10 +307,12 @@ void ProcessProblem(std::vector<Scene>& Scenes, const int ID, bool geom_consiste
     out.depth = Image(height, width, 1);
     out.normal = Image(height, width, 3);
     out.cost = Image(height, width, 1);
+    const float4* host_planes = MP.GetPlaneHypotheses();
+#pragma omp parallel for schedule(static)
     for (int row = 0; row < height; ++row)
         for (int col = 0; col < width; ++col) {
             const int idx = row * width + col;
-            const float4 pl = MP.GetPlaneHypothesis(idx);
+            const float4 pl = host_planes[idx];
             out.depth.at(row, col) = pl.w;
             out.normal.at(row, col, 0) = pl.x;
             out.normal.at(row, col, 1) = pl.y;
@@ -286,11 +320,13 @@ void ProcessProblem(std::vector<Scene>& Scenes, const int ID, bool geom_consiste
             out.cost.at(row, col) = MP.GetCost(idx);
         }
     if (!results) {
-        scene.depth = out.depth;
-        scene.normal = out.normal;
-        scene.cost = out.cost;
+        scene.depth = std::move(out.depth);
+        scene.normal = std::move(out.normal);
+        scene.cost = std::move(out.cost);
     }
+    tm.lap("results");
     MP.Release(Scenes, ID);
+    tm.lap("Release");
 }
 
 // ---------------------------------------------------------------------------

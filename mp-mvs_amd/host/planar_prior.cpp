@@ -123,13 +123,20 @@ struct Mesh {
         const i128 a2 = ax * ax + ay * ay, b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
         return ax * (by * c2 - b2 * cy) - ay * (bx * c2 - b2 * cx) + a2 * (bx * cy - by * cx) > 0;
     }
+    // sign of orient for image points only (64-bit exact)
+    inline long long orient64(int a, int b, int c) const { return (px[b] - px[a]) * (py[c] - py[a]) - (py[b] - py[a]) * (px[c] - px[a]); }
+    inline bool right_of(int a, int b, int p) const {
+        if (a >= 3 && b >= 3) return orient64(a, b, p) < 0;
+        return orient(a, b, p) < 0;
+    }
+    std::vector<int> free_slots;  // slots of deleted triangles are reused: the live mesh stays ~2N entries (cache resident)
     int locate(int p) {
         int t = last;
         for (size_t guard = 0; guard < tris.size() * 3 + 16; ++guard) {
             bool moved = false;
             for (int i = 0; i < 3; ++i) {
                 const int a = tris[t].v[(i + 1) % 3], b = tris[t].v[(i + 2) % 3];
-                if (orient(a, b, p) < 0) {
+                if (right_of(a, b, p)) {
                     t = tris[t].n[i];
                     moved = true;
                     break;
@@ -177,7 +184,10 @@ struct Mesh {
                     for (int j = 0; j < 3; ++j)
                         if (tris[nb].n[j] == t) tris[nb].n[j] = -2 - (int)(edges.size() - 1);
             }
-        for (int t : cavity) dead[t] = 1;
+        for (int t : cavity) {
+            dead[t] = 1;
+            free_slots.push_back(t);
+        }
         for (Edge& e : edges) {
             Tri nt;
             nt.v[0] = p;
@@ -185,9 +195,16 @@ struct Mesh {
             nt.v[2] = e.b;
             nt.n[0] = e.outer;
             nt.n[1] = nt.n[2] = -1;
-            e.tri = (int)tris.size();
-            tris.push_back(nt);
-            dead.push_back(0);
+            if (!free_slots.empty()) {
+                e.tri = free_slots.back();
+                free_slots.pop_back();
+                tris[e.tri] = nt;
+                dead[e.tri] = 0;
+            } else {
+                e.tri = (int)tris.size();
+                tris.push_back(nt);
+                dead.push_back(0);
+            }
         }
         for (size_t k = 0; k < edges.size(); ++k) {
             const Edge& e = edges[k];
@@ -215,8 +232,8 @@ std::vector<Triangle> Delaunay(const Rect boundRC, const std::vector<Point>& poi
     m.py = {-K, -K, 3 * K};
     m.px.reserve(points.size() + 3);
     m.py.reserve(points.size() + 3);
-    m.tris.reserve(points.size() * 7 + 16);
-    m.dead.reserve(points.size() * 7 + 16);
+    m.tris.reserve(points.size() * 2 + 64);
+    m.dead.reserve(points.size() * 2 + 64);
     Tri t0;
     t0.v[0] = 0;
     t0.v[1] = 1;
