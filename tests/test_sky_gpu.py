@@ -64,3 +64,27 @@ def test_sky_masks_through_the_folder_flow(pm, oracle, engine, tmp_path):
     assert np.array_equal(rec[:, :12].copy().view(np.float32), cloud[:, :3])
     assert np.array_equal(rec[:, 24:27], cloud[:, [8, 7, 6]].astype(np.int32).astype(np.uint8))     # PLY stores red, green, blue from B,G,R (reference :181-186)
     assert hostlib.fuse_folder(tmp_path, sky_seg=False) > n_sky
+
+
+def test_sky_and_fuse_argument_errors(pm, engine):
+    """bad arguments come back as error codes / exceptions, never as a fault"""
+    import ctypes as C
+    fusion = importlib.import_module("mp-mvs_amd.fusion")
+    lib, _ = engine.load()
+    lib.mpmvs_sky_bilateral.restype = C.c_int
+    lib.mpmvs_sky_bilateral.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    img = np.zeros((4, 4, 3), np.uint8)
+    m = np.zeros((4, 4), np.float32)
+    o = np.zeros((4, 4), np.float32)
+    assert lib.mpmvs_sky_bilateral(0, None, m.ctypes.data, o.ctypes.data, 4, 4) != 0
+    assert lib.mpmvs_sky_bilateral(0, img.ctypes.data, m.ctypes.data, o.ctypes.data, 0, 4) != 0
+    assert lib.mpmvs_sky_bilateral(99, img.ctypes.data, m.ctypes.data, o.ctypes.data, 4, 4) != 0
+    lib.mpmvs_fuse.restype = C.c_int
+    lib.mpmvs_fuse.argtypes = [C.c_int] + fusion.FUSE_ARGTYPES_TAIL
+    assert lib.mpmvs_fuse(0, 0, None, None, None, None, None, 3, None, None, None, 1, None, None, None) != 0      # n = 0
+    sc, neigh = pm.synth.make_grid_scene(32, 24, 2, 1, spacing=0.4, quantize=True)
+    cams = [v.cam for v in sc.views]
+    d = [v.gt_depth for v in sc.views]
+    n = [np.zeros(x.shape + (3,), np.float32) for x in d]
+    with pytest.raises(AssertionError):
+        fusion.fuse(cams, [True, True], d, n, [np.zeros((24, 32, 2), np.uint8)] * 2, neigh)                         # 2 colour channels
