@@ -167,7 +167,18 @@ int mpmvs_fuse(int device, int n, const mpmvs_camera* cams, const int* estimate,
                const unsigned char* const* sky, const int* src_off, const int* src_ids, int use_dynamic_consistency,
                unsigned char* const* out_valid, float* const* out_points9, unsigned char* const* out_masks);
 
-/* device time (ms, HIP events) of the kernels of the last mpmvs_fuse call */
+/* The same fusion, but the points are compacted on the device and come back as the vertex records of the reference's
+ * binary PLY (StoreColorPlyFileBinaryPointCloud, src/PatchMatch.cpp:145-198): 27 bytes each = x y z nx ny nz (float32)
+ * red green blue (uint8; colors must then be B,G,R or grey), non-finite coordinates zeroed, in the reference's PointCloud
+ * order (image index, then raster).  *records receives a buffer to release with mpmvs_free; out_masks may be NULL.
+ * Returns the number of points, or a negative error code. */
+long long mpmvs_fuse_ply(int device, int n, const mpmvs_camera* cams, const int* estimate, const float* const* depths,
+                         const float* const* normals, const unsigned char* const* colors, int color_channels,
+                         const unsigned char* const* sky, const int* src_off, const int* src_ids, int use_dynamic_consistency,
+                         unsigned char** records, unsigned char* const* out_masks);
+void mpmvs_free(void* p);
+
+/* device time (ms, HIP events) of the kernels of the last mpmvs_fuse / mpmvs_fuse_ply call */
 float mpmvs_fuse_kernel_ms(void);
 
 /* ---- sky-mask refinement --------------------------------------- */

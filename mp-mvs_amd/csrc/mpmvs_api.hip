@@ -16,6 +16,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <atomic>
@@ -68,6 +69,16 @@ static thread_local std::string g_create_err;
             return -100;                                                                            \
         }                                                                                           \
     } while (0)
+
+// hipGetLastError() reports the last error of ANY earlier runtime call of this thread (e.g. another caller's failed
+// hipSetDevice).  Every entry point drops such a stale error first, so that the checks after its own kernel launches only
+// see its own failures.
+static hipError_t enter_device(int device) {
+    (void)hipGetLastError();
+    const hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e;
+}
 
 static int fail(mpmvs_ctx* c, int code, const char* msg) {
     c->err = msg;
@@ -269,7 +280,7 @@ mpmvs_ctx* mpmvs_create(int device) {
         g_create_err = "device index out of range";
         return nullptr;
     }
-    if ((e = hipSetDevice(device)) != hipSuccess) {
+    if ((e = enter_device(device)) != hipSuccess) {
         g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e);
         return nullptr;
     }
@@ -300,7 +311,7 @@ const char* mpmvs_last_error(const mpmvs_ctx* c) { return c ? c->err.c_str() : g
 
 int mpmvs_set_views(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* const* images, const size_t* pitch_bytes) {
     if (!c) return -1;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, enter_device(c->device));
     if (n < 2 || n - 1 > MPMVS_MAX_SRC_VIEWS) return fail(c, -1, "need 2..33 views");
     for (int i = 0; i < n; ++i)
         if (cams[i].width <= 0 || cams[i].height <= 0 || !images[i]) return fail(c, -2, "bad image size or null image");
@@ -377,7 +388,7 @@ static int attach_depths(mpmvs_ctx* c, int n_src, const int* widths, const int* 
 
 int mpmvs_set_src_depths(mpmvs_ctx* c, int n_src, const float* const* depths, const int* widths, const int* heights, const size_t* pitch_bytes) {
     if (!c) return -1;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, enter_device(c->device));
     if (c->n_img < 2 || n_src != c->n_img - 1) return fail(c, -1, "n_src must equal the number of source views");
     for (float* p : c->d_depth) (void)hipFree(p);
     c->d_depth.assign(n_src, nullptr);
@@ -392,7 +403,7 @@ int mpmvs_set_src_depths(mpmvs_ctx* c, int n_src, const float* const* depths, co
 
 int mpmvs_set_src_depths_device(mpmvs_ctx* c, int n_src, const float* const* d_depths, const int* widths, const int* heights) {
     if (!c) return -1;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, enter_device(c->device));
     if (c->n_img < 2 || n_src != c->n_img - 1) return fail(c, -1, "n_src must equal the number of source views");
     for (float* p : c->d_depth) (void)hipFree(p);
     c->d_depth.assign(n_src, nullptr);
@@ -407,7 +418,7 @@ int mpmvs_set_src_depths_device(mpmvs_ctx* c, int n_src, const float* const* d_d
 
 int mpmvs_set_state(mpmvs_ctx* c, const void* planes4, const void* costs) {
     if (!c) return -1;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, enter_device(c->device));
     if (!c->S.planes) return fail(c, -1, "set_views first");
     const size_t wh = (size_t)c->W * c->H;
     if (planes4) HIPCHK(c, hipMemcpyAsync(c->S.planes, planes4, wh * 16, hipMemcpyHostToDevice, c->stream));
@@ -418,7 +429,7 @@ int mpmvs_set_state(mpmvs_ctx* c, const void* planes4, const void* costs) {
 
 int mpmvs_set_selected_views(mpmvs_ctx* c, const void* sel) {
     if (!c) return -1;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, enter_device(c->device));
     if (!c->S.sel) return fail(c, -1, "set_views first");
     HIPCHK(c, hipMemcpyAsync(c->S.sel, sel, (size_t)c->W * c->H * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -427,7 +438,7 @@ int mpmvs_set_selected_views(mpmvs_ctx* c, const void* sel) {
 
 int mpmvs_set_prior(mpmvs_ctx* c, const void* prior4, const void* mask) {
     if (!c) return -1;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, enter_device(c->device));
     if (!c->S.planes) return fail(c, -1, "set_views first");
     const size_t wh = (size_t)c->W * c->H;
     if (!c->d_prior) HIPCHK(c, hipMalloc(&c->d_prior, wh * 16));
@@ -566,7 +577,7 @@ extern "C" {
 
 int mpmvs_run(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed) {
     if (!c || !p) return -1;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, enter_device(c->device));
     int rc = check_ready(c, p);
     if (rc) return rc;
     for (int k = 0; k < 6; ++k) {
@@ -595,7 +606,7 @@ int mpmvs_run(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed) {
 
 int mpmvs_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int kind, int iter, int scale, uint32_t launch_id) {
     if (!c || !p) return -1;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, enter_device(c->device));
     int rc = check_ready(c, p);
     if (rc) return rc;
     if ((rc = enqueue_step(c, p, seed, kind, iter, scale, launch_id))) return rc;
@@ -604,7 +615,7 @@ int mpmvs_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int kind, int
 
 int mpmvs_get(mpmvs_ctx* c, void* planes4, void* costs, void* geom) {
     if (!c) return -1;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, enter_device(c->device));
     if (!c->S.planes) return fail(c, -1, "set_views first");
     const size_t wh = (size_t)c->W * c->H;
     if (planes4) HIPCHK(c, hipMemcpyAsync(planes4, c->S.planes, wh * 16, hipMemcpyDeviceToHost, c->stream));
@@ -616,7 +627,7 @@ int mpmvs_get(mpmvs_ctx* c, void* planes4, void* costs, void* geom) {
 
 int mpmvs_get_selected_views(mpmvs_ctx* c, void* sel) {
     if (!c) return -1;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, enter_device(c->device));
     if (!c->S.sel) return fail(c, -1, "set_views first");
     HIPCHK(c, hipMemcpyAsync(sel, c->S.sel, (size_t)c->W * c->H * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -625,7 +636,7 @@ int mpmvs_get_selected_views(mpmvs_ctx* c, void* sel) {
 
 int mpmvs_export_depth_device(mpmvs_ctx* c, float* d_out) {
     if (!c) return -1;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, enter_device(c->device));
     if (!c->S.planes) return fail(c, -1, "set_views first");
     const int n = c->W * c->H;
     hipLaunchKernelGGL(k_export_depth, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S.planes, d_out, n);
@@ -636,7 +647,7 @@ int mpmvs_export_depth_device(mpmvs_ctx* c, float* d_out) {
 
 int mpmvs_eval_ncc(mpmvs_ctx* c, const mpmvs_params* p, const void* planes_cam4, int scale, void* out) {
     if (!c || !p) return -1;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, enter_device(c->device));
     int rc = check_ready(c, p);
     if (rc) return rc;
     if (scale < 0 || scale > 2) return fail(c, -3, "scale must be 0..2");
@@ -670,7 +681,7 @@ int mpmvs_eval_ncc(mpmvs_ctx* c, const mpmvs_params* p, const void* planes_cam4,
 
 int mpmvs_eval_geom(mpmvs_ctx* c, const mpmvs_params* p, const void* planes_cam4, void* out) {
     if (!c || !p) return -1;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, enter_device(c->device));
     if (c->n_img < 2) return fail(c, -1, "set_views first");
     if (!c->have_depths) return fail(c, -4, "need source depth maps");
     const size_t wh = (size_t)c->W * c->H;
@@ -692,7 +703,7 @@ int mpmvs_eval_geom(mpmvs_ctx* c, const mpmvs_params* p, const void* planes_cam4
 
 int mpmvs_homography(mpmvs_ctx* c, const void* plane4, int v, void* H9) {
     if (!c) return -1;
-    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, enter_device(c->device));
     if (c->n_img < 2 || v < 0 || v >= c->hP.V) return fail(c, -1, "bad source view");
     float* d_h = nullptr;
     HIPCHK(c, hipMalloc(&d_h, 9 * 4));
@@ -707,6 +718,7 @@ int mpmvs_homography(mpmvs_ctx* c, const void* plane4, int v, void* H9) {
 
 int mpmvs_math(int fn, const void* in, void* out, int n) {
     if (fn < 0 || fn > 5 || n <= 0) return -1;
+    (void)hipGetLastError();  // drop a stale error of an earlier call (see enter_device)
     float *d_in = nullptr, *d_out = nullptr;
     if (hipMalloc(&d_in, (size_t)n * 4) != hipSuccess) return -100;
     if (hipMalloc(&d_out, (size_t)n * 4) != hipSuccess) return -100;
@@ -724,6 +736,7 @@ int mpmvs_math(int fn, const void* in, void* out, int n) {
 
 int mpmvs_rng(uint64_t seed, uint32_t pix, uint32_t launch_id, int n, void* out) {
     if (n <= 0) return -1;
+    (void)hipGetLastError();
     float* d_out = nullptr;
     if (hipMalloc(&d_out, (size_t)n * 4) != hipSuccess) return -100;
     int rc = 0;
@@ -738,11 +751,13 @@ static float g_fuse_kernel_ms = 0.0f;
 // device time of the kernels (and mask copies) of the last mpmvs_fuse call, HIP events
 float mpmvs_fuse_kernel_ms(void) { return g_fuse_kernel_ms; }
 
-// depth-map fusion, snapshot formulation (pm_fusion.hpp); host buffers in and out
-int mpmvs_fuse(int device, int n, const mpmvs_camera* cams, const int* estimate, const float* const* depths, const float* const* normals,
-               const unsigned char* const* colors, int color_channels, const unsigned char* const* sky, const int* src_off, const int* src_ids,
-               int use_dynamic, unsigned char* const* out_valid, float* const* out_points9, unsigned char* const* out_masks) {
-    if (n <= 0 || (color_channels != 1 && color_channels != 3) || hipSetDevice(device) != hipSuccess) return -1;
+// depth-map fusion, snapshot formulation (pm_fusion.hpp); host buffers in and out.  With `records` the fused points are
+// compacted on the device into PLY vertex records (reference PointCloud order) and only those cross PCIe.
+static int fuse_impl(int device, int n, const mpmvs_camera* cams, const int* estimate, const float* const* depths, const float* const* normals,
+                     const unsigned char* const* colors, int color_channels, const unsigned char* const* sky, const int* src_off, const int* src_ids,
+                     int use_dynamic, unsigned char* const* out_valid, float* const* out_points9, unsigned char* const* out_masks,
+                     unsigned char** records, long long* n_records) {
+    if (n <= 0 || (color_channels != 1 && color_channels != 3) || enter_device(device) != hipSuccess) return -1;
     std::vector<FuseView> hv(n);
     std::vector<void*> to_free;
     auto dalloc = [&](size_t bytes) -> void* {
@@ -755,8 +770,13 @@ int mpmvs_fuse(int device, int n, const mpmvs_camera* cams, const int* estimate,
     std::vector<unsigned char*> d_valid(n, nullptr);
     std::vector<float*> d_out(n, nullptr);
     std::vector<unsigned char*> d_mask(n, nullptr), d_next(n, nullptr);
+    size_t total_px = 0, max_blocks = 0;
     for (int i = 0; i < n && !rc; ++i) {
         const size_t wh = (size_t)cams[i].width * cams[i].height;
+        if (estimate[i]) {
+            total_px += wh;
+            max_blocks = std::max(max_blocks, (wh + 255) / 256);
+        }
         FuseView& v = hv[i];
         cam_to_dev(cams[i], v.cam);
         v.w = cams[i].width;
@@ -773,7 +793,7 @@ int mpmvs_fuse(int device, int n, const mpmvs_camera* cams, const int* estimate,
         if (hipMemcpy(dd, depths[i], wh * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dn, normals[i], wh * 12, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(dg, colors[i], wh * color_channels, hipMemcpyHostToDevice) != hipSuccess || (dsky && hipMemcpy(dsky, sky[i], wh, hipMemcpyHostToDevice) != hipSuccess) ||
             hipMemset(d_mask[i], 0, wh) != hipSuccess ||
-            hipMemset(d_next[i], 0, wh) != hipSuccess || hipMemset(d_valid[i], 0, wh) != hipSuccess || hipMemset(d_out[i], 0, wh * 36) != hipSuccess)
+            hipMemset(d_next[i], 0, wh) != hipSuccess || hipMemset(d_valid[i], 0, wh) != hipSuccess || (!records && hipMemset(d_out[i], 0, wh * 36) != hipSuccess))
             rc = -100;
         v.depth = dd;
         v.normal = dn;
@@ -785,12 +805,21 @@ int mpmvs_fuse(int device, int n, const mpmvs_camera* cams, const int* estimate,
     }
     FuseView* d_views = nullptr;
     int* d_src = nullptr;
+    int* d_blocks = nullptr;
+    long long* d_base = nullptr;
+    unsigned char* d_records = nullptr;
     if (!rc) {
         d_views = (FuseView*)dalloc(sizeof(FuseView) * n);
         d_src = (int*)dalloc(sizeof(int) * (src_off[n] > 0 ? src_off[n] : 1));
         if (!d_views || !d_src || hipMemcpy(d_views, hv.data(), sizeof(FuseView) * n, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(d_src, src_ids, sizeof(int) * src_off[n], hipMemcpyHostToDevice) != hipSuccess)
             rc = -100;
+    }
+    if (!rc && records) {
+        d_blocks = (int*)dalloc(sizeof(int) * (max_blocks + 1));
+        d_base = (long long*)dalloc(sizeof(long long));
+        d_records = (unsigned char*)dalloc(total_px * kPlyRecord);  // upper bound: every pixel a point
+        if (!d_blocks || !d_base || !d_records || hipMemset(d_base, 0, sizeof(long long)) != hipSuccess) rc = -100;
     }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     (void)hipEventCreate(&ev0);
@@ -808,6 +837,14 @@ int mpmvs_fuse(int device, int n, const mpmvs_camera* cams, const int* estimate,
             const int s = src_ids[b + j];
             if (hipMemcpyAsync(d_mask[s], d_next[s], (size_t)hv[s].w * hv[s].h, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) rc = -100;
         }
+        if (records && !rc) {
+            const int wh = hv[i].w * hv[i].h, nb = (wh + 255) / 256;
+            hipLaunchKernelGGL(k_fuse_count, dim3(nb), dim3(256), 0, nullptr, d_valid[i], wh, d_blocks);
+            hipLaunchKernelGGL(k_fuse_scan, dim3(1), dim3(256), 0, nullptr, d_blocks, nb);
+            hipLaunchKernelGGL(k_fuse_scatter, dim3(nb), dim3(256), 0, nullptr, d_valid[i], d_out[i], wh, d_blocks, d_base, d_records);
+            hipLaunchKernelGGL(k_fuse_advance, dim3(1), dim3(1), 0, nullptr, d_base, d_blocks + nb);
+            if (hipGetLastError() != hipSuccess) rc = -100;
+        }
     }
     (void)hipEventRecord(ev1, nullptr);
     if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -100;
@@ -816,20 +853,57 @@ int mpmvs_fuse(int device, int n, const mpmvs_camera* cams, const int* estimate,
     (void)hipEventDestroy(ev1);
     for (int i = 0; i < n && !rc; ++i) {
         const size_t wh = (size_t)hv[i].w * hv[i].h;
-        if (hipMemcpy(out_valid[i], d_valid[i], wh, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(out_points9[i], d_out[i], wh * 36, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(out_masks[i], d_mask[i], wh, hipMemcpyDeviceToHost) != hipSuccess)
+        if ((out_valid && hipMemcpy(out_valid[i], d_valid[i], wh, hipMemcpyDeviceToHost) != hipSuccess) ||
+            (out_points9 && hipMemcpy(out_points9[i], d_out[i], wh * 36, hipMemcpyDeviceToHost) != hipSuccess) ||
+            (out_masks && hipMemcpy(out_masks[i], d_mask[i], wh, hipMemcpyDeviceToHost) != hipSuccess))
             rc = -100;
+    }
+    if (!rc && records) {
+        long long count = 0;
+        if (hipMemcpy(&count, d_base, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) rc = -100;
+        unsigned char* host = nullptr;
+        if (!rc) {
+            host = (unsigned char*)std::malloc(count > 0 ? (size_t)count * kPlyRecord : 1);
+            if (!host) rc = -101;
+        }
+        if (!rc && count > 0 && hipMemcpy(host, d_records, (size_t)count * kPlyRecord, hipMemcpyDeviceToHost) != hipSuccess) rc = -100;
+        if (rc) {
+            std::free(host);
+        } else {
+            *records = host;
+            *n_records = count;
+        }
     }
     for (void* p : to_free) (void)hipFree(p);
     return rc;
 }
+
+int mpmvs_fuse(int device, int n, const mpmvs_camera* cams, const int* estimate, const float* const* depths, const float* const* normals,
+               const unsigned char* const* colors, int color_channels, const unsigned char* const* sky, const int* src_off, const int* src_ids,
+               int use_dynamic, unsigned char* const* out_valid, float* const* out_points9, unsigned char* const* out_masks) {
+    if (!out_valid || !out_points9 || !out_masks) return -1;
+    return fuse_impl(device, n, cams, estimate, depths, normals, colors, color_channels, sky, src_off, src_ids, use_dynamic, out_valid, out_points9,
+                     out_masks, nullptr, nullptr);
+}
+
+long long mpmvs_fuse_ply(int device, int n, const mpmvs_camera* cams, const int* estimate, const float* const* depths, const float* const* normals,
+                         const unsigned char* const* colors, int color_channels, const unsigned char* const* sky, const int* src_off,
+                         const int* src_ids, int use_dynamic, unsigned char** records, unsigned char* const* out_masks) {
+    if (!records) return -1;
+    long long count = 0;
+    const int rc = fuse_impl(device, n, cams, estimate, depths, normals, colors, color_channels, sky, src_off, src_ids, use_dynamic, nullptr, nullptr,
+                             out_masks, records, &count);
+    return rc ? rc : count;
+}
+
+void mpmvs_free(void* p) { std::free(p); }
 
 static float g_sky_kernel_ms = 0.0f;
 float mpmvs_sky_kernel_ms(void) { return g_sky_kernel_ms; }
 
 // joint-bilateral sky-mask refinement (pm_sky.hpp); host buffers in and out
 int mpmvs_sky_bilateral(int device, const unsigned char* bgr, const float* mask, float* out, int height, int width) {
-    if (!bgr || !mask || !out || height <= 0 || width <= 0 || hipSetDevice(device) != hipSuccess) return -1;
+    if (!bgr || !mask || !out || height <= 0 || width <= 0 || enter_device(device) != hipSuccess) return -1;
     const size_t wh = (size_t)height * width;
     unsigned char* d_img = nullptr;
     float *d_mask = nullptr, *d_out = nullptr;

@@ -145,4 +145,78 @@ __global__ __launch_bounds__(256) void k_fuse(const FuseView* __restrict__ views
         if (used[j] != -1) views[src_ids[j]].mask_next[used[j]] = 1;  // idempotent
 }
 
+// ---------------------------------------------------------------------------
+// Compaction of one image's fused points into the reference's PointCloud order (raster order inside the image; images are
+// appended in index order) as PLY vertex records: x y z nx ny nz (float32) red green blue (uint8), 27 bytes, exactly what
+// StoreColorPlyFileBinaryPointCloud writes (ref src/PatchMatch.cpp:145-198).  Three small passes, deterministic:
+// per-256-pixel block counts -> exclusive scan (one block) -> scatter with in-block ranks.
+// ---------------------------------------------------------------------------
+constexpr int kPlyRecord = 27;
+
+__global__ __launch_bounds__(256) void k_fuse_count(const unsigned char* __restrict__ valid, int n, int* __restrict__ block_counts) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int v = (i < n && valid[i]) ? 1 : 0;
+    __shared__ int wave_sum[4];
+    const unsigned long long b = __ballot(v);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
+}
+
+// block_counts[0 .. nb) -> exclusive prefix sums in place; block_counts[nb] receives the image's point count
+__global__ __launch_bounds__(256) void k_fuse_scan(int* __restrict__ block_counts, int nb) {
+    __shared__ int part[256];
+    const int per = (nb + 255) / 256, lo = min(threadIdx.x * per, nb), hi = min(lo + per, nb);
+    int s = 0;
+    for (int k = lo; k < hi; ++k) s += block_counts[k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int k = 0; k < 256; ++k) {
+            const int c = part[k];
+            part[k] = run;
+            run += c;
+        }
+        block_counts[nb] = run;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int k = lo; k < hi; ++k) {
+        const int c = block_counts[k];
+        block_counts[k] = run;
+        run += c;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fuse_scatter(const unsigned char* __restrict__ valid, const float* __restrict__ pts9, int n,
+                                                      const int* __restrict__ block_offsets, const long long* __restrict__ base,
+                                                      unsigned char* __restrict__ records) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int v = (i < n && valid[i]) ? 1 : 0;
+    __shared__ int wave_sum[4];
+    const unsigned long long b = __ballot(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wave_sum[wv] = __popcll(b);
+    __syncthreads();
+    if (!v) return;
+    int rank = __popcll(b & ((1ull << lane) - 1ull));
+    for (int k = 0; k < wv; ++k) rank += wave_sum[k];
+    const long long slot = *base + block_offsets[blockIdx.x] + rank;
+    const float* p = pts9 + (size_t)i * 9;
+    float rec[6] = {p[0], p[1], p[2], p[3], p[4], p[5]};
+    const float big = 3.402823466e+38f;  // FLT_MAX
+    const bool finite = (rec[0] < big && rec[0] > -big) && (rec[1] < big && rec[1] > -big) && (rec[2] < big && rec[2] >= -big);  // ref :176-178
+    if (!finite) rec[0] = rec[1] = rec[2] = 0.0f;
+    unsigned char* o = records + slot * kPlyRecord;
+    const unsigned char* src = (const unsigned char*)rec;
+    for (int k = 0; k < 24; ++k) o[k] = src[k];
+    o[24] = (unsigned char)(int)p[8];  // red   <- colour[2] (the image is B,G,R; ref :181-186)
+    o[25] = (unsigned char)(int)p[7];  // green
+    o[26] = (unsigned char)(int)p[6];  // blue
+}
+
+// *base += count of the image just scattered (block_counts[nb] from k_fuse_scan)
+__global__ void k_fuse_advance(long long* __restrict__ base, const int* __restrict__ image_count) { *base += *image_count; }
+
 }  // namespace pm

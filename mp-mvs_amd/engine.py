@@ -22,7 +22,7 @@ _EXTRA = {
     "texture_format": (C.c_int, [_P]),
     "get_kernel_times": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
 }
-ALL_SYMBOLS = ["mpmvs_" + n for n in list(_abi.SIGNATURES) + list(_EXTRA)] + ["mpmvs_fuse", "mpmvs_fuse_kernel_ms", "mpmvs_sky_bilateral", "mpmvs_sky_kernel_ms"]
+ALL_SYMBOLS = ["mpmvs_" + n for n in list(_abi.SIGNATURES) + list(_EXTRA)] + ["mpmvs_fuse", "mpmvs_fuse_kernel_ms", "mpmvs_sky_bilateral", "mpmvs_sky_kernel_ms", "mpmvs_fuse_ply", "mpmvs_free"]
 
 _cache = {}
 

@@ -65,6 +65,46 @@ def fuse(cams, estimate, depths, normals, colors, sources, use_dynamic=True, dev
     return call_fuse(fn, (int(device),), cams, estimate, depths, normals, colors, sources, use_dynamic, sky)
 
 
+def ply_records(cloud):
+    """[M, 9] points (x y z nx ny nz c0 c1 c2, colour B,G,R) -> [M, 27] uint8 PLY vertex records as the reference writes them
+    (src/PatchMatch.cpp:145-198): non-finite coordinates zeroed, red green blue = (uchar)(int) of c2 c1 c0"""
+    cloud = np.ascontiguousarray(cloud, np.float32)
+    xyz = cloud[:, :3].copy()
+    big = np.float32(3.402823466e+38)
+    fin = (xyz[:, 0] < big) & (xyz[:, 0] > -big) & (xyz[:, 1] < big) & (xyz[:, 1] > -big) & (xyz[:, 2] < big) & (xyz[:, 2] >= -big)
+    xyz[~fin] = 0
+    rec = np.empty((len(cloud), 27), np.uint8)
+    rec[:, :12] = xyz.view(np.uint8).reshape(-1, 12)
+    rec[:, 12:24] = np.ascontiguousarray(cloud[:, 3:6]).view(np.uint8).reshape(-1, 12)
+    rec[:, 24:27] = cloud[:, [8, 7, 6]].astype(np.int32).astype(np.uint8)
+    return rec
+
+
+def fuse_ply(cams, estimate, depths, normals, colors, sources, use_dynamic=True, device=0, sky=None):
+    """mpmvs_fuse_ply: fusion with device-side compaction; returns ([M, 27] uint8 PLY vertex records, masks list)"""
+    from . import engine
+    lib, _ = engine.load()
+    fn = lib.mpmvs_fuse_ply
+    fn.restype = C.c_longlong
+    fn.argtypes = [C.c_int] + FUSE_ARGTYPES_TAIL[:-3] + [C.POINTER(C.POINTER(C.c_ubyte)), _PP_U8]
+    lib.mpmvs_free.argtypes = [C.c_void_p]
+    lib.mpmvs_free.restype = None
+    out = {}
+
+    def call(*args):
+        # args = (device, n, cams, estimate, depths, normals, colors, ch, sky, off, ids, dyn, valid, points9, masks) from call_fuse
+        rec = C.POINTER(C.c_ubyte)()
+        count = fn(*args[:-3], C.byref(rec), args[-1])
+        if count < 0:
+            return int(count)
+        out["records"] = np.ctypeslib.as_array(rec, shape=(count, 27)).copy() if count else np.zeros((0, 27), np.uint8)
+        lib.mpmvs_free(rec)
+        return 0
+
+    _, _, masks = call_fuse(call, (int(device),), cams, estimate, depths, normals, colors, sources, use_dynamic, sky)
+    return out["records"], masks
+
+
 def last_kernel_ms():
     from . import engine
     lib, _ = engine.load()

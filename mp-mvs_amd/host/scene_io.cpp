@@ -306,6 +306,12 @@ void ProcessProblem(const std::string& input_folder, const std::string& output_f
 // float32, then red green blue as uchar; the colour triple is stored blue-first in
 // PointList::color (OpenCV BGR) and written red-first; non-finite coordinates become 0
 // ---------------------------------------------------------------------------
+static void WritePlyHeader(FILE* out, size_t n_vertices) {
+    fprintf(out, "ply\nformat binary_little_endian 1.0\nelement vertex %zu\n", n_vertices);
+    fprintf(out, "property float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n");
+    fprintf(out, "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n");
+}
+
 void StoreColorPlyFileBinaryPointCloud(const std::string& plyFilePath, const std::vector<PointList>& pc) {
     std::cout << "store 3D points to ply file" << std::endl;
     FILE* out = fopen(plyFilePath.c_str(), "wb");
@@ -313,9 +319,7 @@ void StoreColorPlyFileBinaryPointCloud(const std::string& plyFilePath, const std
         std::cout << "Error opening file " << plyFilePath << std::endl;
         return;
     }
-    fprintf(out, "ply\nformat binary_little_endian 1.0\nelement vertex %zu\n", pc.size());
-    fprintf(out, "property float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n");
-    fprintf(out, "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n");
+    WritePlyHeader(out, pc.size());
     for (const PointList& p : pc) {
         float3 X = p.coord;
         const bool finite = (X.x < FLT_MAX && X.x > -FLT_MAX) && (X.y < FLT_MAX && X.y > -FLT_MAX) && (X.z < FLT_MAX && X.z >= -FLT_MAX);
@@ -431,35 +435,31 @@ long RunFusion(const std::string& input_folder, const std::string& output_folder
     }
     std::vector<const float*> dp(n), np_(n);
     std::vector<const unsigned char*> gp(n), sp(n, nullptr);
-    std::vector<std::vector<unsigned char>> valid(n), masks(n);
-    std::vector<std::vector<float>> pts(n);
-    std::vector<unsigned char*> vp(n), mp(n);
-    std::vector<float*> pp(n);
     for (int i = 0; i < n; ++i) {
-        const size_t wh = (size_t)cams[i].width * cams[i].height;
         dp[i] = depths[i].data.data();
         np_[i] = normals[i].data.data();
         gp[i] = colors[i].data.data();
         if (!sky[i].empty()) sp[i] = sky[i].data.data();
-        valid[i].assign(wh, 0);
-        masks[i].assign(wh, 0);
-        pts[i].assign(wh * 9, 0.0f);
-        vp[i] = valid[i].data();
-        mp[i] = masks[i].data();
-        pp[i] = pts[i].data();
     }
-    if (mpmvs_fuse(device, n, cams.data(), estimate.data(), dp.data(), np_.data(), gp.data(), 3, sky_seg ? sp.data() : nullptr, src_off.data(), src_ids.data(),
-                   use_dynamic_consistency ? 1 : 0, vp.data(), pp.data(), mp.data()) != 0)
+    // the points come back compacted as PLY vertex records (what StoreColorPlyFileBinaryPointCloud would write for the
+    // reference's PointCloud vector): only they cross PCIe
+    unsigned char* records = nullptr;
+    const long long count = mpmvs_fuse_ply(device, n, cams.data(), estimate.data(), dp.data(), np_.data(), gp.data(), 3, sky_seg ? sp.data() : nullptr,
+                                           src_off.data(), src_ids.data(), use_dynamic_consistency ? 1 : 0, &records, nullptr);
+    if (count < 0) return -1;
+    std::cout << "store 3D points to ply file" << std::endl;
+    const std::string ply = output_folder + "/MPMVS_model.ply";
+    FILE* out = fopen(ply.c_str(), "wb");
+    if (!out) {
+        std::cout << "Error opening file " << ply << std::endl;
+        mpmvs_free(records);
         return -1;
-    std::vector<PointList> cloud;
-    for (int i = 0; i < n; ++i)
-        for (size_t k = 0; k < valid[i].size(); ++k)
-            if (valid[i][k]) {
-                const float* p = &pts[i][k * 9];
-                cloud.push_back(PointList{float3{p[0], p[1], p[2]}, float3{p[3], p[4], p[5]}, float3{p[6], p[7], p[8]}});
-            }
-    StoreColorPlyFileBinaryPointCloud(output_folder + "/MPMVS_model.ply", cloud);
-    return (long)cloud.size();
+    }
+    WritePlyHeader(out, (size_t)count);
+    const bool ok = fwrite(records, 27, (size_t)count, out) == (size_t)count;
+    fclose(out);
+    mpmvs_free(records);
+    return ok ? (long)count : -1;
 }
 
 // ---------------------------------------------------------------------------

@@ -60,3 +60,23 @@ def test_fusion_of_estimated_maps(pm, oracle, engine):
     assert np.array_equal(cg, cc) and all(np.array_equal(a, b) for a, b in zip(mg, mc))
     err = np.abs(cg[:, 2] - pm.synth.height_field(cg[:, 0].astype(np.float64), cg[:, 1].astype(np.float64)))
     assert len(cg) > 300 and np.median(err) < 0.05   # 128x96 single-pass estimates: few pixels meet 1 % / 10 degrees
+
+
+@pytest.mark.parametrize("use_sky", [False, True])
+def test_fuse_ply_records_equal_uncompacted_path(pm, oracle, engine, use_sky):
+    """mpmvs_fuse_ply (device-side compaction into PLY vertex records) == the records built from mpmvs_fuse's per-pixel
+    outputs == those built from the oracle's cloud, in the reference's PointCloud order; sizes that are not block multiples"""
+    fusion = importlib.import_module("mp-mvs_amd.fusion")
+    sc, cams, depths, normals, grays, neigh = _scene(pm, size=(131, 97))
+    cols, sky = _colours_and_sky(grays)
+    depths[1][5:9, 7:40] = np.inf                      # non-finite coordinates are written as 0 (reference :176-179)
+    est = [True, True, False, True, True, True]
+    sky = sky if use_sky else None
+    rec, masks = fusion.fuse_ply(cams, est, depths, normals, cols, neigh, sky=sky)
+    cloud, _, masks2 = fusion.fuse(cams, est, depths, normals, cols, neigh, sky=sky)
+    cloud_o, _, _ = oracle.fuse(cams, est, depths, normals, cols, neigh, sky=sky)
+    assert rec.shape == (len(cloud), 27) and len(cloud) > 1000
+    assert np.array_equal(rec, fusion.ply_records(cloud)) and np.array_equal(rec, fusion.ply_records(cloud_o))
+    assert all(np.array_equal(a, b) for a, b in zip(masks, masks2))
+    rec0, _ = fusion.fuse_ply(cams, [False] * 6, depths, normals, cols, neigh)
+    assert rec0.shape == (0, 27)
