@@ -14,10 +14,14 @@ sc, cams, depths, normals, grays, neigh = _scene(pm, n_grid=(4, 2), size=(1600, 
 fusion.fuse(cams, [True] * 8, depths, normals, grays, neigh)  # warm-up (library load)
 t0 = time.perf_counter(); cg, vg, mg = fusion.fuse(cams, [True] * 8, depths, normals, grays, neigh); tg = time.perf_counter() - t0
 kms = fusion.last_kernel_ms()
+cols = [np.stack([g, 255 - g, g // 2], -1).astype(np.uint8) for g in (np.asarray(x).astype(np.uint8) for x in grays)]
+fusion.fuse_ply(cams, [True] * 8, depths, normals, cols, neigh)
+t0 = time.perf_counter(); rec, _ = fusion.fuse_ply(cams, [True] * 8, depths, normals, cols, neigh); tp = time.perf_counter() - t0
+kms_ply = fusion.last_kernel_ms()
 ob.set_num_threads(min(16, len(os.sched_getaffinity(0))))
 t0 = time.perf_counter(); cc, vc, mc = ob.fuse(cams, [True] * 8, depths, normals, grays, neigh); tc = time.perf_counter() - t0
 t0 = time.perf_counter(); cs, vs, ms = ob.fuse(cams, [True] * 8, depths, normals, grays, neigh, sequential_literal=True); ts = time.perf_counter() - t0
-print(json.dumps({"images": 8, "size": [1600, 1200], "points": int(len(cg)), "gpu_incl_transfers_s": round(tg, 3), "oracle_snapshot_16thr_s": round(tc, 3),
+print(json.dumps({"fuse_ply_bgr_incl_transfers_s": round(tp, 3), "fuse_ply_kernels_ms": round(kms_ply, 3), "fuse_ply_points": int(len(rec)), "images": 8, "size": [1600, 1200], "points": int(len(cg)), "gpu_incl_transfers_s": round(tg, 3), "oracle_snapshot_16thr_s": round(tc, 3),
                   "oracle_sequential_literal_s": round(ts, 3), "bit_exact": bool(np.array_equal(cg, cc)), "points_sequential": int(len(cs)),
                   "Mpix_per_s_gpu": round(8 * 1600 * 1200 / tg / 1e6, 1), "gpu_kernels_ms": round(kms, 3),
                   "algorithmic_GB": round(8 * 1600 * 1200 * (21 + 7 * 21 + 37) / 1e9, 2), "GBps_kernels": round(8 * 1600 * 1200 * (21 + 7 * 21 + 37) / (kms * 1e-3) / 1e9, 1)}))
