@@ -22,6 +22,10 @@
 #include <atomic>
 #include <thread>
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "../../include/mpmvs.h"
@@ -85,22 +89,101 @@ static int fail(mpmvs_ctx* c, int code, const char* msg) {
     return code;
 }
 
+// ---------------------------------------------------------------------------
+// Device-buffer pool.  A context is created and destroyed per ProcessProblem call in the reference's flow (three times
+// per Problem with the shipped schedule) and always asks for the same two dozen buffer sizes; hipMalloc/hipFree cost
+// ~0.1-0.3 ms each and hipFree synchronises the device.  Released buffers are therefore kept per (device, size) and handed
+// out again; at most MPMVS_POOL_MB (default 4096, 0 = off) megabytes are held.  Callers synchronise the owning stream
+// before they release a buffer, so a pooled buffer is never still in use.
+// ---------------------------------------------------------------------------
+namespace {
+struct BufPool {
+    std::mutex mu;
+    std::unordered_map<void*, std::pair<int, size_t>> owner;
+    std::map<std::pair<int, size_t>, std::vector<void*>> cached;
+    size_t cached_bytes = 0;
+    size_t cap = 4096ull << 20;
+    BufPool() {
+        if (const char* e = std::getenv("MPMVS_POOL_MB")) cap = (size_t)std::strtoull(e, nullptr, 10) << 20;
+    }
+    void trim_locked() {
+        for (auto& kv : cached)
+            for (void* p : kv.second) {
+                owner.erase(p);
+                (void)hipFree(p);
+            }
+        cached.clear();
+        cached_bytes = 0;
+    }
+};
+BufPool g_pool;
+}  // namespace
+
+static hipError_t pool_malloc_bytes(void** p, size_t bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        auto it = g_pool.cached.find({dev, bytes});
+        if (it != g_pool.cached.end() && !it->second.empty()) {
+            *p = it->second.back();
+            it->second.pop_back();
+            g_pool.cached_bytes -= bytes;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {  // out of memory with buffers parked in the pool: give them back and retry once
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        g_pool.trim_locked();
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        g_pool.owner[*p] = {dev, bytes};
+    }
+    return e;
+}
+template <typename T>
+static hipError_t pool_malloc(T** p, size_t bytes) {
+    return pool_malloc_bytes((void**)p, bytes);
+}
+static hipError_t pool_free(void* p) {
+    if (!p) return hipSuccess;
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        auto it = g_pool.owner.find(p);
+        if (it != g_pool.owner.end()) {
+            const size_t bytes = it->second.second;
+            if (g_pool.cached_bytes + bytes <= g_pool.cap) {
+                g_pool.cached[it->second].push_back(p);
+                g_pool.cached_bytes += bytes;
+                return hipSuccess;
+            }
+            g_pool.owner.erase(it);
+        }
+    }
+    return hipFree(p);
+}
+
 static void free_views(mpmvs_ctx* c) {
-    if (c->d_ref) (void)hipFree(c->d_ref);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);  // nothing may still use what goes back to the pool
+    if (c->d_ref) (void)pool_free(c->d_ref);
     c->d_ref = nullptr;
-    for (float* p : c->d_src) (void)hipFree(p);
+    for (float* p : c->d_src) (void)pool_free(p);
     c->d_src.clear();
-    for (uint32_t* p : c->d_src8) (void)hipFree(p);
+    for (uint32_t* p : c->d_src8) (void)pool_free(p);
     c->d_src8.clear();
     c->all_u8 = false;
-    for (float* p : c->d_depth) (void)hipFree(p);
+    for (float* p : c->d_depth) (void)pool_free(p);
     c->d_depth.clear();
-    if (c->S.planes) (void)hipFree(c->S.planes);
-    if (c->S.costs) (void)hipFree(c->S.costs);
-    if (c->S.sel) (void)hipFree(c->S.sel);
-    if (c->S.geom) (void)hipFree(c->S.geom);
-    if (c->d_prior) (void)hipFree(c->d_prior);
-    if (c->d_mask) (void)hipFree(c->d_mask);
+    if (c->S.planes) (void)pool_free(c->S.planes);
+    if (c->S.costs) (void)pool_free(c->S.costs);
+    if (c->S.sel) (void)pool_free(c->S.sel);
+    if (c->S.geom) (void)pool_free(c->S.geom);
+    if (c->d_prior) (void)pool_free(c->d_prior);
+    if (c->d_mask) (void)pool_free(c->d_mask);
     c->S = StateDev{};
     c->d_prior = nullptr;
     c->d_mask = nullptr;
@@ -173,15 +256,15 @@ static int upload_problem(mpmvs_ctx* c) {
 // host image -> dense staging buffer -> replicate-padded resident image
 static int upload_padded(mpmvs_ctx* c, const float* host, size_t pitch, int w, int h, int apron, float** out) {
     float* d_raw = nullptr;
-    HIPCHK(c, hipMalloc(&d_raw, (size_t)w * h * 4));
+    HIPCHK(c, pool_malloc(&d_raw, (size_t)w * h * 4));
     HIPCHK(c, hipMemcpy2DAsync(d_raw, (size_t)w * 4, host, pitch, (size_t)w * 4, h, hipMemcpyHostToDevice, c->stream));
     const int pw = w + 2 * apron, ph = h + 2 * apron;
     float* d_pad = nullptr;
-    HIPCHK(c, hipMalloc(&d_pad, (size_t)pw * ph * 4));
+    HIPCHK(c, pool_malloc(&d_pad, (size_t)pw * ph * 4));
     hipLaunchKernelGGL(k_pad, dim3((pw + 255) / 256, ph), dim3(256), 0, c->stream, d_raw, w, h, d_pad, apron);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipFree(d_raw));
+    HIPCHK(c, pool_free(d_raw));
     *out = d_pad;
     return 0;
 }
@@ -189,14 +272,14 @@ static int upload_padded(mpmvs_ctx* c, const float* host, size_t pitch, int w, i
 // host image -> dense staging buffer -> quad-packed fp32 texture (w x h float4)
 static int upload_extended(mpmvs_ctx* c, const float* host, size_t pitch, int w, int h, float** out) {
     float* d_raw = nullptr;
-    HIPCHK(c, hipMalloc(&d_raw, (size_t)w * h * 4));
+    HIPCHK(c, pool_malloc(&d_raw, (size_t)w * h * 4));
     HIPCHK(c, hipMemcpy2DAsync(d_raw, (size_t)w * 4, host, pitch, (size_t)w * 4, h, hipMemcpyHostToDevice, c->stream));
     float* d_e = nullptr;
-    HIPCHK(c, hipMalloc(&d_e, (size_t)w * h * 16));
+    HIPCHK(c, pool_malloc(&d_e, (size_t)w * h * 16));
     hipLaunchKernelGGL(k_pack_quads_f32, dim3((w + 255) / 256, h), dim3(256), 0, c->stream, d_raw, w, h, (float4*)d_e);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipFree(d_raw));
+    HIPCHK(c, pool_free(d_raw));
     *out = d_e;
     return 0;
 }
@@ -206,7 +289,7 @@ static int upload_extended(mpmvs_ctx* c, const float* host, size_t pitch, int w,
 static int upload_quads_u8(mpmvs_ctx* c, const unsigned char* host8, unsigned char* d_stage, int w, int h, uint32_t** out) {
     HIPCHK(c, hipMemcpyAsync(d_stage, host8, (size_t)w * h, hipMemcpyHostToDevice, c->stream));
     uint32_t* d_q = nullptr;
-    HIPCHK(c, hipMalloc(&d_q, (size_t)w * h * 4));
+    HIPCHK(c, pool_malloc(&d_q, (size_t)w * h * 4));
     *out = d_q;  // owned by the context from here on (freed by free_views also on a later error)
     hipLaunchKernelGGL(k_pack_quads_u8, dim3((w + 255) / 256, h), dim3(256), 0, c->stream, d_stage, w, h, d_q);
     HIPCHK(c, hipGetLastError());
@@ -339,7 +422,7 @@ int mpmvs_set_views(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* 
     if (exact) {
         size_t biggest = 0;
         for (int v = 1; v < n; ++v) biggest = std::max(biggest, (size_t)cams[v].width * cams[v].height);
-        HIPCHK(c, hipMalloc(&d_stage, biggest));
+        HIPCHK(c, pool_malloc(&d_stage, biggest));
     }
     for (int v = 1; v < n; ++v) {
         const int w = cams[v].width, h = cams[v].height;
@@ -348,7 +431,7 @@ int mpmvs_set_views(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* 
         if (exact) {
             if ((rc = upload_quads_u8(c, src8[v - 1].data(), d_stage, w, h, &c->d_src8[v - 1]))) {
                 (void)hipStreamSynchronize(c->stream);
-                (void)hipFree(d_stage);
+                (void)pool_free(d_stage);
                 return rc;
             }
             o.pitch8 = w;
@@ -360,16 +443,16 @@ int mpmvs_set_views(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* 
         }
     }
     const size_t wh = (size_t)c->W * c->H;
-    HIPCHK(c, hipMalloc(&c->S.planes, wh * 16));
-    HIPCHK(c, hipMalloc(&c->S.costs, wh * 4));
-    HIPCHK(c, hipMalloc(&c->S.sel, wh * 4));
-    HIPCHK(c, hipMalloc(&c->S.geom, wh * 4));
+    HIPCHK(c, pool_malloc(&c->S.planes, wh * 16));
+    HIPCHK(c, pool_malloc(&c->S.costs, wh * 4));
+    HIPCHK(c, pool_malloc(&c->S.sel, wh * 4));
+    HIPCHK(c, pool_malloc(&c->S.geom, wh * 4));
     HIPCHK(c, hipMemsetAsync(c->S.planes, 0, wh * 16, c->stream));
     HIPCHK(c, hipMemsetAsync(c->S.costs, 0, wh * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->S.sel, 0, wh * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->S.geom, 0, wh * 4, c->stream));
     rc = upload_problem(c);  // synchronises the stream: the staged 8-bit copies are complete
-    if (d_stage) (void)hipFree(d_stage);
+    if (d_stage) (void)pool_free(d_stage);
     return rc;
 }
 
@@ -390,11 +473,12 @@ int mpmvs_set_src_depths(mpmvs_ctx* c, int n_src, const float* const* depths, co
     if (!c) return -1;
     HIPCHK(c, enter_device(c->device));
     if (c->n_img < 2 || n_src != c->n_img - 1) return fail(c, -1, "n_src must equal the number of source views");
-    for (float* p : c->d_depth) (void)hipFree(p);
+    (void)hipStreamSynchronize(c->stream);
+    for (float* p : c->d_depth) (void)pool_free(p);
     c->d_depth.assign(n_src, nullptr);
     for (int i = 0; i < n_src; ++i) {
         if (widths[i] <= 0 || heights[i] <= 0 || !depths[i]) return fail(c, -2, "bad depth map");
-        HIPCHK(c, hipMalloc(&c->d_depth[i], (size_t)widths[i] * heights[i] * 4));
+        HIPCHK(c, pool_malloc(&c->d_depth[i], (size_t)widths[i] * heights[i] * 4));
         const size_t pitch = pitch_bytes ? pitch_bytes[i] : (size_t)widths[i] * 4;
         HIPCHK(c, hipMemcpy2DAsync(c->d_depth[i], (size_t)widths[i] * 4, depths[i], pitch, (size_t)widths[i] * 4, heights[i], hipMemcpyHostToDevice, c->stream));
     }
@@ -405,12 +489,13 @@ int mpmvs_set_src_depths_device(mpmvs_ctx* c, int n_src, const float* const* d_d
     if (!c) return -1;
     HIPCHK(c, enter_device(c->device));
     if (c->n_img < 2 || n_src != c->n_img - 1) return fail(c, -1, "n_src must equal the number of source views");
-    for (float* p : c->d_depth) (void)hipFree(p);
+    (void)hipStreamSynchronize(c->stream);
+    for (float* p : c->d_depth) (void)pool_free(p);
     c->d_depth.assign(n_src, nullptr);
     for (int i = 0; i < n_src; ++i) {
         if (widths[i] <= 0 || heights[i] <= 0 || !d_depths[i]) return fail(c, -2, "bad depth map");
         const size_t bytes = (size_t)widths[i] * heights[i] * 4;
-        HIPCHK(c, hipMalloc(&c->d_depth[i], bytes));
+        HIPCHK(c, pool_malloc(&c->d_depth[i], bytes));
         HIPCHK(c, hipMemcpyAsync(c->d_depth[i], d_depths[i], bytes, hipMemcpyDeviceToDevice, c->stream));
     }
     return attach_depths(c, n_src, widths, heights);
@@ -441,8 +526,8 @@ int mpmvs_set_prior(mpmvs_ctx* c, const void* prior4, const void* mask) {
     HIPCHK(c, enter_device(c->device));
     if (!c->S.planes) return fail(c, -1, "set_views first");
     const size_t wh = (size_t)c->W * c->H;
-    if (!c->d_prior) HIPCHK(c, hipMalloc(&c->d_prior, wh * 16));
-    if (!c->d_mask) HIPCHK(c, hipMalloc(&c->d_mask, wh * 4));
+    if (!c->d_prior) HIPCHK(c, pool_malloc(&c->d_prior, wh * 16));
+    if (!c->d_mask) HIPCHK(c, pool_malloc(&c->d_mask, wh * 4));
     HIPCHK(c, hipMemcpyAsync(c->d_prior, prior4, wh * 16, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_mask, mask, wh * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -762,7 +847,7 @@ static int fuse_impl(int device, int n, const mpmvs_camera* cams, const int* est
     std::vector<void*> to_free;
     auto dalloc = [&](size_t bytes) -> void* {
         void* p = nullptr;
-        if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return nullptr;
+        if (pool_malloc_bytes(&p, bytes ? bytes : 4) != hipSuccess) return nullptr;
         to_free.push_back(p);
         return p;
     };
@@ -874,7 +959,8 @@ static int fuse_impl(int device, int n, const mpmvs_camera* cams, const int* est
             *n_records = count;
         }
     }
-    for (void* p : to_free) (void)hipFree(p);
+    (void)hipDeviceSynchronize();  // also on an error path: nothing may still use what goes back to the pool
+    for (void* p : to_free) (void)pool_free(p);
     return rc;
 }
 
@@ -908,7 +994,7 @@ int mpmvs_sky_bilateral(int device, const unsigned char* bgr, const float* mask,
     unsigned char* d_img = nullptr;
     float *d_mask = nullptr, *d_out = nullptr;
     int rc = 0;
-    if (hipMalloc(&d_img, wh * 3) != hipSuccess || hipMalloc(&d_mask, wh * 4) != hipSuccess || hipMalloc(&d_out, wh * 4) != hipSuccess) rc = -100;
+    if (pool_malloc(&d_img, wh * 3) != hipSuccess || pool_malloc(&d_mask, wh * 4) != hipSuccess || pool_malloc(&d_out, wh * 4) != hipSuccess) rc = -100;
     if (!rc && (hipMemcpy(d_img, bgr, wh * 3, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_mask, mask, wh * 4, hipMemcpyHostToDevice) != hipSuccess)) rc = -100;
     if (!rc) {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -925,9 +1011,10 @@ int mpmvs_sky_bilateral(int device, const unsigned char* bgr, const float* mask,
         (void)hipEventDestroy(ev1);
     }
     if (!rc && hipMemcpy(out, d_out, wh * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = -100;
-    (void)hipFree(d_img);
-    (void)hipFree(d_mask);
-    (void)hipFree(d_out);
+    (void)hipDeviceSynchronize();
+    (void)pool_free(d_img);
+    (void)pool_free(d_mask);
+    (void)pool_free(d_out);
     return rc;
 }
 
