@@ -28,11 +28,12 @@ for V in (8, 12, 16, 20, 24):
     upd = (ms[1] + ms[2]) / (cnt[1] + cnt[2])
     sel = h.get_selected_views()
     pc = np.array([bin(int(x)).count("1") for x in sel.ravel()]).reshape(sel.shape)
-    un = []
+    un, mx = [], []
     for y in range(0, H - 16, 16):
         for x in range(0, W - 16, 16):
             blk = sel[y:y + 16, x:x + 16]     # one colour of a 16x16 area = a 16x8 wave patch
             un.append(bin(int(np.bitwise_or.reduce(blk.ravel()))).count("1"))
+            mx.append(int(pc[y:y + 16, x:x + 16].max()))
     out[f"V{V}"] = {"update_ms": round(upd, 3), "ns_per_eval_nominal": round(upd * 1e6 / (W * H / 2 * 14 * V), 3),
-                    "selected_per_pixel": round(float(pc.mean()), 2), "selected_per_wave_union": round(float(np.mean(un)), 2)}
+                    "selected_per_pixel": round(float(pc.mean()), 2), "selected_per_wave_union": round(float(np.mean(un)), 2), "selected_per_wave_max": round(float(np.mean(mx)), 2)}
 print(json.dumps(out))
