@@ -474,3 +474,21 @@ def test_geom_and_prior_with_many_views_bit_exact(pm, oracle, engine):
         prm.geom_consistency, prm.planar_prior, prm.max_iterations = False, True, 3
         h.run(prm, SEED + 2)
     compare_state(gpu, cpu, "prior")
+
+
+def test_max_image_size_bit_exact(pm, oracle, engine):
+    """the largest image the reference processes (`Max image size: 3200`, config/config.yaml:20 -> 3200x2400): one photometric
+    red/black iteration with 2 source views on the HIP path == oracle (index arithmetic, texture offsets and block remapping at 7.7 Mpix)"""
+    W, H = 3200, 2400
+    sc = pm.synth.make_problem_scene(W, H, n_src=2, quantize=True)
+    cams, imgs = sc.problem(0, [1, 2])
+    dmin, dmax = pm.synth.kernel_depth_range(cams[0])
+    p = pm.PatchMatchParams(num_images=3, depth_min=float(dmin), depth_max=float(dmax), max_scale=0, max_iterations=1)
+    gpu, cpu = engine.create(0), oracle.create()
+    for h in (gpu, cpu):
+        h.set_views(cams, imgs)
+        h.run(p, 5)
+    gp, gc = gpu.get()
+    cp, cc = cpu.get()
+    assert np.array_equal(gp, cp) and np.array_equal(gc, cc)
+    assert np.array_equal(gpu.get_selected_views(), cpu.get_selected_views())
