@@ -91,22 +91,15 @@ void PatchMatchCUDA::PatchMatchInit(std::vector<Scene>& Scenes, const int ID) {
     cameras.clear();
     std::vector<int>& srcID = Scenes[ID].srcID;
     num_img = (int)srcID.size();
+    // Adjust image scale (reference src/PatchMatch.cpp:893-925): images larger than max_image_size are shrunk with bilinear
+    // interpolation and K follows.  The reference re-reads and re-shrinks the files on every call; here the Scene caches the
+    // shrunk image, so the scaled intrinsics are cached with it (s.cam) -- a later call finds a consistent pair.
     for (int i = 0; i < num_img; ++i) {
         Scene& s = Scenes[srcID[i]];
         if (s.image.empty()) {
             std::cout << "Can not read this image !" << srcID[i] << std::endl;
             exit(EXIT_FAILURE);
         }
-        images.push_back(&s.image);
-        Camera cam = s.cam;
-        cam.height = s.image.rows;
-        cam.width = s.image.cols;
-        cameras.push_back(cam);
-    }
-    // Adjust image scale (reference src/PatchMatch.cpp:893-925): images larger than
-    // max_image_size are shrunk with bilinear interpolation and K follows
-    for (int i = 0; i < num_img; ++i) {
-        Scene& s = Scenes[srcID[i]];
         const int max_image_size = s.max_image_size;
         if (s.image.cols <= max_image_size && s.image.rows <= max_image_size) continue;
         const float factor_x = static_cast<float>(max_image_size) / s.image.cols;
@@ -117,13 +110,18 @@ void PatchMatchCUDA::PatchMatchInit(std::vector<Scene>& Scenes, const int ID) {
         const float scale_x = new_cols / static_cast<float>(s.image.cols);
         const float scale_y = new_rows / static_cast<float>(s.image.rows);
         s.image = ResizeLinear(s.image, new_cols, new_rows);
-        images[i] = &s.image;
-        cameras[i].K[0] *= scale_x;
-        cameras[i].K[2] *= scale_x;
-        cameras[i].K[4] *= scale_y;
-        cameras[i].K[5] *= scale_y;
-        cameras[i].height = new_rows;
-        cameras[i].width = new_cols;
+        s.cam.K[0] *= scale_x;
+        s.cam.K[2] *= scale_x;
+        s.cam.K[4] *= scale_y;
+        s.cam.K[5] *= scale_y;
+    }
+    for (int i = 0; i < num_img; ++i) {
+        Scene& s = Scenes[srcID[i]];
+        images.push_back(&s.image);
+        Camera cam = s.cam;
+        cam.height = s.image.rows;
+        cam.width = s.image.cols;
+        cameras.push_back(cam);
     }
     params.depth_min = cameras[0].depth_min * 0.6f;  // reference :929-930
     params.depth_max = cameras[0].depth_max * 1.2f;
@@ -400,12 +398,13 @@ int mpmvs_host_resize_linear(const float* src, int w, int h, float* dst, int new
 // reference schedules it.  images[0]/cams[0] is the reference view.
 int mpmvs_host_run_pipeline(int device, int n, const mpmvs_camera* cams, const float* const* images, int max_scale,
                             int geom_iterations, int planar_prior, int geomPlanarPrior, uint64_t seed,
-                            const float* const* src_depths, float* out_depth, float* out_normal3, float* out_cost) {
+                            const float* const* src_depths, float* out_depth, float* out_normal3, float* out_cost, int max_image_size) {
     std::vector<Scene> Scenes(n);
     for (int i = 0; i < n; ++i) {
         Scene& s = Scenes[i];
         s.refID = i;
         s.cam = cams[i];
+        if (max_image_size > 0) s.max_image_size = max_image_size;
         s.image = Image(cams[i].height, cams[i].width, 1);
         std::memcpy(s.image.data.data(), images[i], s.image.data.size() * sizeof(float));
         if (i > 0 && src_depths) {

@@ -31,7 +31,7 @@ def load():
         lib.mpmvs_host_build_prior.argtypes = [C.POINTER(_abi.Camera), C.c_int, C.c_int, P, P, P, C.c_int, C.c_float, C.c_float, P, P]
         lib.mpmvs_host_run_pipeline.restype = C.c_int
         lib.mpmvs_host_run_pipeline.argtypes = [C.c_int, C.c_int, C.POINTER(_abi.Camera), C.POINTER(C.POINTER(C.c_float)), C.c_int, C.c_int,
-                                                C.c_int, C.c_int, C.c_uint64, C.POINTER(C.POINTER(C.c_float)), P, P, P]
+                                                C.c_int, C.c_int, C.c_uint64, C.POINTER(C.POINTER(C.c_float)), P, P, P, C.c_int]
         lib.mpmvs_host_write_dmb.restype = C.c_int
         lib.mpmvs_host_write_dmb.argtypes = [C.c_char_p, P, C.c_int, C.c_int, C.c_int]
         lib.mpmvs_host_read_dmb.restype = C.c_int
@@ -96,8 +96,9 @@ def build_prior(cam, planes, costs, geom_costs, geom_planar_prior, depth_min, de
     return prior, mask, n
 
 
-def run_pipeline(device, cams, images, max_scale, geom_iterations, planar_prior, geom_planar_prior, seed, src_depths=None):
-    """one Problem through the reference's pass schedule on the HIP path; returns depth, normal, cost"""
+def run_pipeline(device, cams, images, max_scale, geom_iterations, planar_prior, geom_planar_prior, seed, src_depths=None, max_image_size=0, out_size=None):
+    """one Problem through the reference's pass schedule on the HIP path; returns depth, normal, cost.
+    max_image_size > 0: larger images are shrunk as PatchMatchInit does (out_size = (h, w) of the shrunk reference image)"""
     lib = load()
     n = len(cams)
     imgs = [np.ascontiguousarray(im, np.float32) for im in images]
@@ -107,12 +108,12 @@ def run_pipeline(device, cams, images, max_scale, geom_iterations, planar_prior,
     if src_depths is not None:
         ds = [np.ascontiguousarray(d, np.float32) for d in src_depths]
         dptr = (C.POINTER(C.c_float) * (n - 1))(*[d.ctypes.data_as(C.POINTER(C.c_float)) for d in ds])
-    h, w = imgs[0].shape
+    h, w = out_size if out_size is not None else imgs[0].shape
     depth = np.empty((h, w), np.float32)
     normal = np.empty((h, w, 3), np.float32)
     cost = np.empty((h, w), np.float32)
     rc = lib.mpmvs_host_run_pipeline(int(device), n, cam_arr, ptrs, int(max_scale), int(geom_iterations), 1 if planar_prior else 0,
-                                     1 if geom_planar_prior else 0, int(seed), dptr, depth.ctypes.data, normal.ctypes.data, cost.ctypes.data)
+                                     1 if geom_planar_prior else 0, int(seed), dptr, depth.ctypes.data, normal.ctypes.data, cost.ctypes.data, int(max_image_size))
     if rc != 0:
         raise RuntimeError(f"mpmvs_host_run_pipeline failed ({rc})")
     return depth, normal, cost

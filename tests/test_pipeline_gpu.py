@@ -46,6 +46,33 @@ def oracle_pipeline(pm, oracle, hostlib, cams, imgs, src_depths, max_scale, geom
     return state["planes"], state["costs"]
 
 
+def test_oversized_images_are_shrunk_once_and_k_follows(pm, oracle, engine):
+    """PatchMatchInit's "Adjust image scale" (reference src/PatchMatch.cpp:893-925): images above max_image_size are shrunk
+    (INTER_LINEAR) and K is scaled; the Scene caches the shrunk image together with the scaled K, so the second Run() of the
+    planar-prior schedule and later passes see a consistent pair.  HIP pipeline == oracle on the shrunk inputs."""
+    import copy
+    hostlib = importlib.import_module("mp-mvs_amd.hostlib")
+    sc = pm.synth.make_problem_scene(160, 120, n_src=3, spacing=0.4, quantize=True)
+    cams, imgs = sc.problem(0, [1, 2, 3])
+    new_w, new_h = 100, 75                                   # factor min(100/160, 100/120) = 0.625
+    # photometric Run() + planar-prior Run(): two Run()s on the cached, shrunk scene
+    depth, normal, cost = hostlib.run_pipeline(0, cams, imgs, 1, 0, True, False, 99, None, max_image_size=100, out_size=(new_h, new_w))
+    small_imgs = [hostlib.resize_linear(im, new_w, new_h) for im in imgs]
+    sx, sy = np.float32(new_w) / np.float32(160), np.float32(new_h) / np.float32(120)
+    small_cams = []
+    for c in cams:
+        k = copy.copy(c)
+        K = np.array(list(c.K), np.float32)
+        K[0], K[2], K[4], K[5] = K[0] * sx, K[2] * sx, K[4] * sy, K[5] * sy
+        for j in range(9):
+            k.K[j] = float(K[j])
+        k.width, k.height = new_w, new_h
+        small_cams.append(k)
+    planes, costs = oracle_pipeline(pm, oracle, hostlib, small_cams, small_imgs, None, 1, 0, True, False, 99)
+    assert depth.shape == (new_h, new_w)
+    assert np.array_equal(depth, planes[..., 3]) and np.array_equal(normal, planes[..., :3]) and np.array_equal(cost, costs)
+
+
 @pytest.mark.parametrize("geom_iterations,planar_prior,geom_pp,max_scale", [(1, False, False, 2),   # cfg 2
                                                                            (2, True, True, 2),      # cfg 3 (shipped config.yaml)
                                                                            (0, True, False, 0)])    # photometric + prior
