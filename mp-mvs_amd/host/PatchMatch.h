@@ -96,12 +96,14 @@ struct Scene {
 
 // bilinear resize used by PatchMatchInit's "Adjust image scale" (reference src/PatchMatch.cpp:893-925)
 Image ResizeLinear(const Image& src, int new_cols, int new_rows);
+// that step for one Scene: an image above s.max_image_size is shrunk in place and s.cam.K follows (no-op otherwise)
+void AdjustImageScale(Scene& s);
 
 class PatchMatchCUDA {
    private:
     int num_img = 0;
     std::vector<const Image*> images;
-    std::vector<Image> depths;
+    std::vector<const Image*> depths;  // source depth maps of the previous pass (owned by the Scenes)
     std::vector<Camera> cameras;
     mpmvs_ctx* ctx = nullptr;  // replaces reference PatchMatch.h:95-117
     int device = 0;

@@ -85,6 +85,23 @@ struct StageTimer {
     }
 };
 
+void AdjustImageScale(Scene& s) {
+    const int max_image_size = s.max_image_size;
+    if (s.image.empty() || (s.image.cols <= max_image_size && s.image.rows <= max_image_size)) return;
+    const float factor_x = static_cast<float>(max_image_size) / s.image.cols;
+    const float factor_y = static_cast<float>(max_image_size) / s.image.rows;
+    const float factor = std::min(factor_x, factor_y);
+    const int new_cols = (int)std::round(s.image.cols * factor);
+    const int new_rows = (int)std::round(s.image.rows * factor);
+    const float scale_x = new_cols / static_cast<float>(s.image.cols);
+    const float scale_y = new_rows / static_cast<float>(s.image.rows);
+    s.image = ResizeLinear(s.image, new_cols, new_rows);
+    s.cam.K[0] *= scale_x;
+    s.cam.K[2] *= scale_x;
+    s.cam.K[4] *= scale_y;
+    s.cam.K[5] *= scale_y;
+}
+
 void PatchMatchCUDA::PatchMatchInit(std::vector<Scene>& Scenes, const int ID) {
     images.clear();
     depths.clear();
@@ -100,20 +117,7 @@ void PatchMatchCUDA::PatchMatchInit(std::vector<Scene>& Scenes, const int ID) {
             std::cout << "Can not read this image !" << srcID[i] << std::endl;
             exit(EXIT_FAILURE);
         }
-        const int max_image_size = s.max_image_size;
-        if (s.image.cols <= max_image_size && s.image.rows <= max_image_size) continue;
-        const float factor_x = static_cast<float>(max_image_size) / s.image.cols;
-        const float factor_y = static_cast<float>(max_image_size) / s.image.rows;
-        const float factor = std::min(factor_x, factor_y);
-        const int new_cols = (int)std::round(s.image.cols * factor);
-        const int new_rows = (int)std::round(s.image.rows * factor);
-        const float scale_x = new_cols / static_cast<float>(s.image.cols);
-        const float scale_y = new_rows / static_cast<float>(s.image.rows);
-        s.image = ResizeLinear(s.image, new_cols, new_rows);
-        s.cam.K[0] *= scale_x;
-        s.cam.K[2] *= scale_x;
-        s.cam.K[4] *= scale_y;
-        s.cam.K[5] *= scale_y;
+        AdjustImageScale(s);
     }
     for (int i = 0; i < num_img; ++i) {
         Scene& s = Scenes[srcID[i]];
@@ -133,7 +137,7 @@ void PatchMatchCUDA::PatchMatchInit(std::vector<Scene>& Scenes, const int ID) {
                 std::cout << "Can not read this depth image !" << std::endl;
                 exit(EXIT_FAILURE);
             }
-            depths.push_back(s.depth);
+            depths.push_back(&s.depth);
         }
     }
 }
@@ -163,7 +167,8 @@ void PatchMatchCUDA::CudaMemInit(Scene& scene) {
     if (params.geom_consistency) {
         std::vector<const float*> dptr;
         std::vector<int> ws, hs;
-        for (const Image& d : depths) {
+        for (const Image* dp : depths) {
+            const Image& d = *dp;
             dptr.push_back(d.data.data());
             ws.push_back(d.cols);
             hs.push_back(d.rows);

@@ -12,6 +12,8 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cfloat>
 #include <cstdio>
 #include <cstring>
@@ -302,6 +304,77 @@ void ProcessProblem(const std::string& input_folder, const std::string& output_f
 }
 
 // ---------------------------------------------------------------------------
+// Jacobi pass schedule with worker threads (see scene_io.h)
+// ---------------------------------------------------------------------------
+int RunFolderJacobi(const std::string& input_folder, int max_src, int max_image_size, int geom_iterations, bool planar_prior,
+                    bool geomPlanarPrior, int max_scale, uint64_t seed, const std::vector<int>& devices, int workers) {
+    std::vector<Scene> Scenes;
+    GenerateSampleList(input_folder, max_src, max_image_size > 0 ? max_image_size : 3200, Scenes);
+    const int n = (int)Scenes.size();
+    if (n == 0 || devices.empty()) return -1;
+    const std::string out = input_folder + "/MPMVS";
+    mkdir(out.c_str(), 0777);
+    // every image that is a reference or a source: decode, read its camera, shrink if oversized -- once, in parallel,
+    // so that the Problems only READ the Scenes afterwards
+    std::vector<char> needed(n, 0);
+    for (const Scene& s : Scenes)
+        if (s.estimate)
+            for (int id : s.srcID)
+                if (id >= 0 && id < n) needed[id] = 1;
+    std::atomic<bool> ok(true);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < n; ++i) {
+        if (!needed[i]) continue;
+        Scene& s = Scenes[i];
+        if (!readGrayImage(FindImageFile(input_folder + "/images", i), s.image)) {
+            ok = false;
+            continue;
+        }
+        s.cam = ReadCamera(input_folder + "/cams/" + id8(i) + "_cam.txt");
+        AdjustImageScale(s);
+    }
+    if (!ok) {
+        std::cout << "Can not read every image of " << input_folder << "/images" << std::endl;
+        return -1;
+    }
+    std::vector<int> todo;
+    for (int i = 0; i < n; ++i)
+        if (Scenes[i].estimate) todo.push_back(i);
+    const int nworkers = std::max(1, std::min(workers, (int)todo.size()));
+    auto run_pass = [&](bool geom, bool pp, uint64_t pass_seed) {
+        std::vector<ProblemResult> results(n);
+        std::atomic<size_t> next(0);
+        auto work = [&](int worker) {
+            const int device = devices[worker % devices.size()];
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= todo.size()) return;
+                const int i = todo[k];
+                ProcessProblem(Scenes, i, geom, pp, pass_seed + (uint64_t)i, device, max_scale, &results[i]);
+                const std::string folder = out + "/2333_" + id8(Scenes[i].refID);
+                mkdir(folder.c_str(), 0777);
+                writeDepthDmb(folder + "/depths.dmb", results[i].depth);
+                writeNormalDmb(folder + "/normals.dmb", results[i].normal);
+                writeDepthDmb(folder + "/costs.dmb", results[i].cost);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int w = 1; w < nworkers; ++w) pool.emplace_back(work, w);
+        work(0);
+        for (std::thread& t : pool) t.join();
+        // the barrier of the pass: only now do the new maps become what the next pass reads
+        for (int i : todo) {
+            Scenes[i].depth = std::move(results[i].depth);
+            Scenes[i].normal = std::move(results[i].normal);
+            Scenes[i].cost = std::move(results[i].cost);
+        }
+    };
+    run_pass(false, !geomPlanarPrior && planar_prior, seed);
+    for (int g = 0; g < geom_iterations; ++g) run_pass(true, geomPlanarPrior && g != geom_iterations - 1, seed + 100003ull * (g + 1));
+    return (int)todo.size();
+}
+
+// ---------------------------------------------------------------------------
 // binary PLY of fused points (reference src/PatchMatch.cpp:145-198): x y z nx ny nz as
 // float32, then red green blue as uchar; the colour triple is stored blue-first in
 // PointList::color (OpenCV BGR) and written red-first; non-finite coordinates become 0
@@ -563,6 +636,12 @@ int mpmvs_host_decode_jpeg(const unsigned char* bytes, size_t size, int channels
     }
     if (data && capacity >= px.size()) std::memcpy(data, px.data(), px.size());
     return 0;
+}
+// devices: n_devices device indices (NULL = device 0); returns the number of Problems per pass or -1
+int mpmvs_host_run_folder_jacobi(const char* input_folder, const int* devices, int n_devices, int workers, int max_src, int geom_iterations,
+                                 int planar_prior, int geomPlanarPrior, int max_scale, uint64_t seed, int max_image_size) {
+    std::vector<int> dev(devices && n_devices > 0 ? std::vector<int>(devices, devices + n_devices) : std::vector<int>{0});
+    return RunFolderJacobi(input_folder, max_src, max_image_size, geom_iterations, planar_prior != 0, geomPlanarPrior != 0, max_scale, seed, dev, workers);
 }
 int mpmvs_host_run_folder(const char* input_folder, int device, int max_src, int geom_iterations, int planar_prior,
                           int geomPlanarPrior, int max_scale, uint64_t seed, int max_image_size) {

@@ -48,6 +48,13 @@ bool bilateral_filter(const Image8& img_bgr, const Image& mask, Image& result, i
 // network's output as the reference stores it, <input>/MPMVS/2333_<id>/skymask.{jpg,pgm} (8 bit = 255 x probability), resizes
 // image and mask as :21-34 do, refines, and writes skymask_refine.pgm (0 / 255) beside it.  Returns the number of masks written or -1.
 int RefineSkyMasks(const std::string& input_folder, const std::vector<Scene>& Scenes, int max_image_size, int device = 0);
+// The pass loops of the reference's main() (src/main.cpp:20-41) over a dataset folder in the JACOBI order of DESIGN.md
+// section 7: every Problem of a pass reads the previous pass's maps (kept in memory), so the Problems of a pass are
+// independent and are processed by `workers` host threads dealt round-robin to `devices` -- the Delaunay / file work of
+// one Problem overlaps the kernels of others, and several GPUs are used from one process.  Results do not depend on
+// workers or devices, and equal SceneScheduler's (mp-mvs_amd/schedule.py).  Writes the same depths/normals/costs.dmb files.
+int RunFolderJacobi(const std::string& input_folder, int max_src, int max_image_size, int geom_iterations, bool planar_prior,
+                    bool geomPlanarPrior, int max_scale, uint64_t seed, const std::vector<int>& devices, int workers);
 void ProcessProblem(const std::string& input_folder, const std::string& output_folder, std::vector<Scene>& Scenes, const int ID,
                     bool geom_consistency, bool planar_prior, uint64_t seed = 0, int device = 0, int max_scale = 2);
 

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "host", "libmpmvs_host.so")
 SYMBOLS = ["mpmvs_host_triangulate_vertices", "mpmvs_host_delaunay", "mpmvs_host_build_prior", "mpmvs_host_run_pipeline",
            "mpmvs_host_write_dmb", "mpmvs_host_read_dmb", "mpmvs_host_read_camera", "mpmvs_host_sample_list", "mpmvs_host_read_pgm",
            "mpmvs_host_run_folder", "mpmvs_host_resize_linear", "mpmvs_host_write_ply", "mpmvs_host_fuse_folder", "mpmvs_host_read_image",
-           "mpmvs_host_decode_jpeg", "mpmvs_host_refine_sky_masks"]
+           "mpmvs_host_decode_jpeg", "mpmvs_host_refine_sky_masks", "mpmvs_host_run_folder_jacobi"]
 _cache = {}
 
 
@@ -44,6 +44,8 @@ def load():
         lib.mpmvs_host_read_pgm.argtypes = [C.c_char_p, P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.mpmvs_host_run_folder.restype = C.c_int
         lib.mpmvs_host_run_folder.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int]
+        lib.mpmvs_host_run_folder_jacobi.restype = C.c_int
+        lib.mpmvs_host_run_folder_jacobi.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int]
         lib.mpmvs_host_fuse_folder.restype = C.c_long
         lib.mpmvs_host_fuse_folder.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
         lib.mpmvs_host_refine_sky_masks.restype = C.c_int
@@ -196,6 +198,18 @@ def run_folder(folder, device=0, max_src=20, geom_iterations=2, planar_prior=Tru
                                       1 if geom_planar_prior else 0, max_scale, seed, max_image_size)
     if rc != 0:
         raise RuntimeError(f"run_folder failed ({rc})")
+
+
+def run_folder_jacobi(folder, devices=(0,), workers=3, max_src=20, geom_iterations=2, planar_prior=True, geom_planar_prior=True, max_scale=2, seed=12345,
+                      max_image_size=3200):
+    """the pass loops over a dataset folder in Jacobi order with `workers` host threads over `devices` (see scene_io.h);
+    returns the number of Problems per pass"""
+    dev = (C.c_int * len(devices))(*devices)
+    rc = load().mpmvs_host_run_folder_jacobi(str(folder).encode(), dev, len(devices), workers, max_src, geom_iterations, 1 if planar_prior else 0,
+                                             1 if geom_planar_prior else 0, max_scale, seed, max_image_size)
+    if rc < 0:
+        raise RuntimeError(f"run_folder_jacobi failed ({rc})")
+    return rc
 
 
 def write_dataset(folder, cams, images, sources, scores=None, fmt="pgm", jpeg_options=None):

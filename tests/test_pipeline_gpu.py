@@ -195,7 +195,8 @@ def test_end_to_end_scene_tool(pm, engine, tmp_path):
     assert raw.startswith(b"ply\n") and len(raw.split(b"end_header\n", 1)[1]) == rep["fused_points"] * 27
 
 
-def test_config_driven_main_flow(pm, engine, tmp_path):
+@pytest.mark.parametrize("jacobi_workers", [0, 2])
+def test_config_driven_main_flow(pm, engine, tmp_path, jacobi_workers):
     """tools/mpmvs_main.py = the reference's main() (src/main.cpp:6-55) with its config.yaml keys: JPEG images in,
     depth-map passes, sky-mask refinement, fusion, PLY out"""
     import json
@@ -218,7 +219,7 @@ def test_config_driven_main_flow(pm, engine, tmp_path):
                    'Geometric consistency planer prior: 0\nSky segment: 1\nUse dynamic_consistency to fuse: 1\nSave Dmb as JPG: 1\n'
                    'Max source images num: 20\nMax image size: 3200\n')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "mpmvs_main.py"), "--config", str(cfg), "--seed", "7"],
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "mpmvs_main.py"), "--config", str(cfg), "--seed", "7", "--jacobi-workers", str(jacobi_workers)],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     rep = json.loads(out.stdout.strip().splitlines()[-1])
@@ -230,3 +231,32 @@ def test_config_driven_main_flow(pm, engine, tmp_path):
     assert np.median(err) < 0.05
     for i in range(6):
         assert (tmp_path / "MPMVS" / f"2333_{i:08d}" / "skymask_refine.pgm").exists() and (tmp_path / "MPMVS" / f"2333_{i:08d}" / "depths.dmb").exists()
+
+
+def test_folder_jacobi_workers_equal_the_scheduler(pm, engine, tmp_path):
+    """RunFolderJacobi (C++, worker threads over a dataset folder) == SceneScheduler (Python, one process per GPU) on the same
+    scene, seeds and schedule: both implement the Jacobi order of DESIGN.md section 7; the result does not depend on the
+    number of workers"""
+    hostlib = importlib.import_module("mp-mvs_amd.hostlib")
+    schedule = importlib.import_module("mp-mvs_amd.schedule")
+    sc, neigh = pm.synth.make_grid_scene(96, 72, 3, 2, spacing=0.4, rot_deg=1.0, quantize=True)
+    cams = [v.cam for v in sc.views]
+    imgs = [v.image for v in sc.views]
+    out = {}
+    for workers in (3, 1):
+        d = tmp_path / f"w{workers}"
+        hostlib.write_dataset(str(d), cams, imgs, neigh)
+        assert hostlib.run_folder_jacobi(d, devices=(0,), workers=workers, geom_iterations=2, planar_prior=True, geom_planar_prior=True, max_scale=1, seed=321) == 6
+        out[workers] = [tuple(hostlib.read_dmb(d / "MPMVS" / f"2333_{i:08d}" / f"{k}.dmb") for k in ("depths", "normals", "costs")) for i in range(6)]
+    for a, b in zip(out[3], out[1]):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    file_cams = []
+    for i in range(6):
+        c = hostlib.read_camera(tmp_path / "w1" / "cams" / f"{i:08d}_cam.txt")
+        c.height, c.width = imgs[i].shape
+        file_cams.append(c)
+    sched = schedule.SceneScheduler(file_cams, imgs, neigh, lambda: engine.create(0), max_scale=1, workers=2)
+    res = sched.run(geom_iterations=2, planar_prior=True, geom_planar_prior=True, seed=321)
+    for i in range(6):
+        planes, costs, _ = res[i]
+        assert np.array_equal(out[3][i][0], planes[..., 3]) and np.array_equal(out[3][i][1], planes[..., :3]) and np.array_equal(out[3][i][2], costs), f"image {i}"

@@ -32,6 +32,10 @@ def main():
     ap.add_argument("--config", required=True)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--seed", type=int, default=int(time.time()))    # the reference seeds from clock64()
+    ap.add_argument("--jacobi-workers", type=int, default=0,
+                    help="0 (default): the reference's sequential, in-place pass order; N > 0: Jacobi order (every pass reads the previous "
+                         "pass's maps) with N host threads, which overlaps the host work of one image with the kernels of others")
+    ap.add_argument("--devices", default=None, help="comma-separated GPU indices for --jacobi-workers (default: --device)")
     a = ap.parse_args()
     cfg = read_config(a.config)
     folder = str(cfg["Input-folder"]).rstrip("/")
@@ -42,8 +46,12 @@ def main():
     max_src = int(cfg.get("Max source images num", 20))
     max_size = int(cfg.get("Max image size", 3200))
     t0 = time.perf_counter()
-    hostlib.run_folder(folder, a.device, max_src, int(cfg.get("Geometric consistency iterations", 2)), bool(cfg.get("Planer prior", 1)),
-                       bool(cfg.get("Geometric consistency planer prior", 1)), 2, a.seed, max_size)
+    schedule = (int(cfg.get("Geometric consistency iterations", 2)), bool(cfg.get("Planer prior", 1)), bool(cfg.get("Geometric consistency planer prior", 1)))
+    if a.jacobi_workers > 0:
+        devices = tuple(int(d) for d in a.devices.split(",")) if a.devices else (a.device,)
+        hostlib.run_folder_jacobi(folder, devices, a.jacobi_workers, max_src, *schedule, 2, a.seed, max_size)
+    else:
+        hostlib.run_folder(folder, a.device, max_src, *schedule, 2, a.seed, max_size)
     t1 = time.perf_counter()
     sky = bool(cfg.get("Sky segment", 0))
     n_masks = hostlib.refine_sky_masks(folder, a.device, max_src, max_size) if sky else 0
