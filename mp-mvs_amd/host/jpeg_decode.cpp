@@ -131,6 +131,7 @@ struct Decoder {
     bool progressive = false, have_frame = false;
     int restart_interval = 0;
     int adobe_transform = -1;
+    int orientation = 1;  // EXIF tag 0x0112 (cv::imread applies it unless IMREAD_IGNORE_ORIENTATION is given)
     Comp comp[3];
 
     bool fail(const char* m) {
@@ -143,6 +144,7 @@ struct Decoder {
     bool read_dht(const uint8_t* s, int len);
     bool read_sof(const uint8_t* s, int len);
     bool read_scan(const uint8_t* s, int len, size_t& pos);
+    void read_exif(const uint8_t* s, int len);
     void reconstruct();
 };
 
@@ -222,6 +224,31 @@ bool Decoder::read_sof(const uint8_t* s, int len) {
     }
     have_frame = true;
     return true;
+}
+
+// APP1 "Exif\0\0" + TIFF header + IFD0: only the orientation tag is of interest
+void Decoder::read_exif(const uint8_t* s, int len) {
+    if (len < 14 || std::memcmp(s, "Exif\0\0", 6) != 0) return;
+    const uint8_t* t = s + 6;
+    const int n = len - 6;
+    const bool le = t[0] == 'I' && t[1] == 'I';
+    if (!le && !(t[0] == 'M' && t[1] == 'M')) return;
+    auto u16 = [&](int o) { return le ? (t[o] | t[o + 1] << 8) : (t[o] << 8 | t[o + 1]); };
+    auto u32 = [&](int o) { return le ? ((uint32_t)t[o] | (uint32_t)t[o + 1] << 8 | (uint32_t)t[o + 2] << 16 | (uint32_t)t[o + 3] << 24)
+                                      : ((uint32_t)t[o] << 24 | (uint32_t)t[o + 1] << 16 | (uint32_t)t[o + 2] << 8 | (uint32_t)t[o + 3]); };
+    if (u16(2) != 42) return;
+    const uint32_t ifd = u32(4);
+    if (ifd + 2 > (uint32_t)n) return;
+    const int entries = u16((int)ifd);
+    for (int e = 0; e < entries; ++e) {
+        const uint32_t o = ifd + 2 + 12u * e;
+        if (o + 12 > (uint32_t)n) return;
+        if (u16((int)o) == 0x0112 && u16((int)o + 2) == 3) {  // SHORT
+            const int v = u16((int)o + 8);
+            if (v >= 1 && v <= 8) orientation = v;
+            return;
+        }
+    }
 }
 
 // ---- one scan ----------------------------------------------------------------------------
@@ -618,6 +645,9 @@ bool Decoder::parse() {
             case 0xEE:
                 if (len >= 12 && std::memcmp(s, "Adobe", 5) == 0) adobe_transform = s[11];
                 break;
+            case 0xE1:
+                read_exif(s, len);
+                break;
             default:
                 break;  // APPn, COM, DNL, ...
         }
@@ -627,6 +657,32 @@ bool Decoder::parse() {
 }
 
 }  // namespace
+
+// EXIF orientations 2..8 -> upright image (what cv::imread returns): 2 mirror, 3 rotate 180, 4 flip, 5 transpose,
+// 6 rotate 90 clockwise, 7 transverse, 8 rotate 90 counter-clockwise
+static void apply_orientation(int orientation, int channels, std::vector<uint8_t>& px, int& w, int& h) {
+    if (orientation <= 1 || orientation > 8) return;
+    const bool swap = orientation >= 5;
+    const int nw = swap ? h : w, nh = swap ? w : h;
+    std::vector<uint8_t> out(px.size());
+    for (int y = 0; y < nh; ++y)
+        for (int x = 0; x < nw; ++x) {
+            int sx, sy;
+            switch (orientation) {
+                case 2: sx = w - 1 - x; sy = y; break;
+                case 3: sx = w - 1 - x; sy = h - 1 - y; break;
+                case 4: sx = x; sy = h - 1 - y; break;
+                case 5: sx = y; sy = x; break;
+                case 6: sx = y; sy = h - 1 - x; break;
+                case 7: sx = w - 1 - y; sy = h - 1 - x; break;
+                default: sx = w - 1 - y; sy = x; break;  // 8
+            }
+            std::memcpy(&out[((size_t)y * nw + x) * channels], &px[((size_t)sy * w + sx) * channels], channels);
+        }
+    px.swap(out);
+    w = nw;
+    h = nh;
+}
 
 bool DecodeJpeg(const uint8_t* data, size_t size, int channels, std::vector<uint8_t>& pixels, int& width, int& height, std::string& err) {
     if (channels != 1 && channels != 3) {
@@ -660,11 +716,13 @@ bool DecodeJpeg(const uint8_t* data, size_t size, int channels, std::vector<uint
     upsample(d.comp[0], d.hmax, d.vmax, W, H, y);
     if (channels == 1) {
         pixels.swap(y);
+        apply_orientation(d.orientation, 1, pixels, width, height);
         return true;
     }
     pixels.resize((size_t)W * H * 3);
     if (d.ncomp == 1) {
         for (size_t i = 0; i < (size_t)W * H; ++i) pixels[3 * i] = pixels[3 * i + 1] = pixels[3 * i + 2] = y[i];
+        apply_orientation(d.orientation, 3, pixels, width, height);
         return true;
     }
     upsample(d.comp[1], d.hmax, d.vmax, W, H, cb);
@@ -691,6 +749,7 @@ bool DecodeJpeg(const uint8_t* data, size_t size, int channels, std::vector<uint
             pixels[3 * i + 0] = clamp8(yy + cb_b[cb[i]]);
         }
     }
+    apply_orientation(d.orientation, 3, pixels, width, height);
     return true;
 }
 

@@ -17,7 +17,7 @@
 // channels = 1: luminance plane (what IMREAD_GRAYSCALE returns for a YCbCr or grey file);
 // channels = 3: interleaved B,G,R (cv::Vec3b order).  Supports 8-bit Huffman-coded baseline,
 // extended-sequential and progressive files with 1 or 3 components, restart intervals, any
-// sampling factors up to 4.  Returns false and fills err otherwise.
+// sampling factors up to 4; an EXIF orientation tag is applied, as cv::imread does.  Returns false and fills err otherwise.
 bool DecodeJpeg(const uint8_t* data, size_t size, int channels, std::vector<uint8_t>& pixels, int& width, int& height, std::string& err);
 bool DecodeJpegFile(const std::string& path, int channels, std::vector<uint8_t>& pixels, int& width, int& height, std::string& err);
 

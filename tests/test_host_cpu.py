@@ -226,6 +226,24 @@ def test_jpeg_decoder_equals_libjpeg(hostlib, size, options):
     assert np.array_equal(hostlib.decode_jpeg(data, 3)[..., ::-1], rgb)
 
 
+@pytest.mark.parametrize("orientation", range(1, 9))
+def test_jpeg_exif_orientation_is_applied(hostlib, orientation):
+    """cv::imread turns the image upright according to EXIF tag 0x0112 (flags without IMREAD_IGNORE_ORIENTATION, as the
+    reference's calls); so does the decoder -- checked against PIL's exif_transpose for all 8 orientations"""
+    import io
+    Image = pytest.importorskip("PIL.Image")
+    from PIL import ImageOps
+    pic = _test_picture(53, 37)
+    ex = Image.Exif()
+    ex[0x0112] = orientation
+    buf = io.BytesIO()
+    Image.fromarray(pic).save(buf, "JPEG", quality=90, exif=ex)
+    data = buf.getvalue()
+    want = np.asarray(ImageOps.exif_transpose(Image.open(io.BytesIO(data))).convert("RGB"))
+    assert np.array_equal(hostlib.decode_jpeg(data, 3)[..., ::-1], want)
+    assert hostlib.decode_jpeg(data, 1).shape == want.shape[:2]
+
+
 def test_jpeg_decoder_rejects_bad_input(hostlib):
     import io
     Image = pytest.importorskip("PIL.Image")
