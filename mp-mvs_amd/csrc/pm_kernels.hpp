@@ -1,8 +1,8 @@
 // pm_kernels.hpp -- the __global__ kernels of the PatchMatch hot path for gfx950.
 //
-// One thread owns one reference pixel (64-wide wavefront = 16x8 pixel patch of
+// One thread owns one reference pixel (64-wide wavefront = 32x4 pixel patch of
 // one checkerboard colour, or an 8x8 patch for the all-pixel kernels), keeps
-// the 36 bilateral weights of its window in registers, and walks the 14
+// the 36 bilateral weight records of its window in LDS, and walks the 14
 // hypotheses of an update through ONE copy of the unrolled 36-tap NCC loop
 // ("slot loop"), so the hot code stays small in the instruction cache.
 // MFMA is not used: there is no dense contraction on this path.
@@ -50,10 +50,11 @@ __device__ constexpr int kNumDirs[8] = {12, 12, 12, 12, 10, 10, 10, 10};
 
 // Wave shape of the checkerboard launches: PM_WAVE_ROWS rows of 64/PM_WAVE_ROWS
 // same-colour pixels; a 256-thread block stacks its 4 waves vertically.
-// Measured (update launch, cfg 1): 8 rows (16x8 patch) 8.13 ms, 4 rows 8.45,
-// 2 rows 8.59, 1 row 8.87 -- compact 2-D patches reuse more L1 lines between taps.
+// Measured (update launch, cfg 1).  Early kernel (gathers serialised): 8 rows (16x8 px patch) 8.13 ms, 4 rows 8.45,
+// 2 rows 8.59, 1 row 8.87 -- compact 2-D patches reuse more L1 lines between taps.  Final kernel (LDS weights, pipelined
+// gathers): 4 rows (32x4 px) 3.853, 8 rows 3.891, 2 rows 3.981, 16 rows 4.835; geometric mode 4.81 vs 5.13.
 #ifndef PM_WAVE_ROWS
-#define PM_WAVE_ROWS 8
+#define PM_WAVE_ROWS 4
 #endif
 constexpr int kLanesPerRow = 64 / PM_WAVE_ROWS;
 constexpr int kChkBlockW = 2 * kLanesPerRow;   // pixels

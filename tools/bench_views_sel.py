@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""how many source views carry weight after the Monte-Carlo view selection, per pixel and per 16x8 wave patch,
+"""how many source views carry weight after the Monte-Carlo view selection, per pixel and per 64-pixel wave patch,
 as a function of V (distinct views on a 5x5 camera grid), and the update-kernel time (800x600)"""
 import importlib, json, os, sys
 import numpy as np
@@ -31,7 +31,7 @@ for V in (8, 12, 16, 20, 24):
     un, mx = [], []
     for y in range(0, H - 16, 16):
         for x in range(0, W - 16, 16):
-            blk = sel[y:y + 16, x:x + 16]     # one colour of a 16x16 area = a 16x8 wave patch
+            blk = sel[y:y + 16, x:x + 16]     # one colour of a 16x16 area ~ the 64 pixels of a wave
             un.append(bin(int(np.bitwise_or.reduce(blk.ravel()))).count("1"))
             mx.append(int(pc[y:y + 16, x:x + 16].max()))
     out[f"V{V}"] = {"update_ms": round(upd, 3), "ns_per_eval_nominal": round(upd * 1e6 / (W * H / 2 * 14 * V), 3),
