@@ -37,6 +37,12 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def hostlib(pm):
+    """ctypes view of libmpmvs_host.so (C++ host layer); it links libmpmvs_hip.so but needs no GPU to load"""
+    return importlib.import_module("mp-mvs_amd.hostlib")
+
+
+@pytest.fixture(scope="session")
 def engine():
     """The HIP library; GPU tests fail (not skip) if it is missing."""
     eng = importlib.import_module("mp-mvs_amd.engine")
