@@ -28,4 +28,18 @@ p.geom_consistency, p.max_iterations = True, 2
 h.run(p, 4)
 ms, cnt = h.kernel_times()
 out["geom_run"] = {"update_total_ms": round(ms[1] + ms[2], 3), "launches": cnt[1] + cnt[2], "init_ms": round(ms[0], 3)}
+# planar-prior mode: prior planes from the true surface normal/depth (fronto-parallel approximation), mask on 60 % of the pixels
+u, v = np.meshgrid(np.arange(W), np.arange(H))
+gt = sc.views[0].gt_depth
+cam = cams[0]
+X = np.stack([gt * (u - cam.K[2]) / cam.K[0], gt * (v - cam.K[5]) / cam.K[4], gt], -1)
+prior = np.zeros((H, W, 4), np.float32)
+prior[..., 2] = -1.0
+prior[..., 3] = X[..., 2]
+mask = (rng.uniform(size=(H, W)) < 0.6).astype(np.uint32)
+h.set_prior(prior, mask)
+p.geom_consistency, p.planar_prior, p.max_iterations = False, True, 3
+h.run(p, 5)
+ms, cnt = h.kernel_times()
+out["prior_run"] = {"update_total_ms": round(ms[1] + ms[2], 3), "launches": cnt[1] + cnt[2], "init_ms": round(ms[0], 3)}
 print(json.dumps(out))
