@@ -1,0 +1,31 @@
+#!/bin/bash
+# Texture-addresser / L1 (TA, TCP, TD) utilisation of the update kernel: is the gather path, not the VALU, the limiter?
+# Run on the GPU box via gpurun; each counter group in its own rocprofv3 pass.
+set -o pipefail
+OUT=$PWD/gpurun_out/prof_ta
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
+# at most 2 counters of one hardware block per pass ("Request exceeds the capabilities of the hardware" otherwise, after
+# which rocprofv3 aborts and hangs); every pass bounded by timeout and announced, so a stuck pass cannot look like a hung run
+pass() { n=$1; shift; echo "pass $n: $*"; timeout -k 10 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$n -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $OUT/$n.err || echo "pass $n failed"; }
+pass ta_a TA_TA_BUSY TA_BUFFER_WAVEFRONTS GRBM_GUI_ACTIVE
+pass ta_b TA_BUFFER_TOTAL_CYCLES TA_ADDR_STALLED_BY_TC_CYCLES
+pass ta_c TA_ADDR_STALLED_BY_TD_CYCLES TA_DATA_STALLED_BY_TC_CYCLES
+pass tcp_a TCP_GATE_EN1 TCP_GATE_EN2 TCP_TCP_TA_DATA_STALL_CYCLES TCP_TD_TCP_STALL_CYCLES
+pass tcp_b TCP_TOTAL_CACHE_ACCESSES TCP_TCP_LATENCY TCP_READ_TAGCONFLICT_STALL_CYCLES TCP_TCR_TCP_STALL_CYCLES
+pass td_a TD_TD_BUSY TD_TC_STALL
+pass td_b TD_LOAD_WAVEFRONT TD_SPI_STALL
+python3 - <<'PY'
+import csv, glob, collections, os
+out = os.environ.get("OUT") or "gpurun_out/prof_ta"
+for n in ("ta_a", "ta_b", "ta_c", "tcp_a", "tcp_b", "td_a", "td_b"):
+    fs = glob.glob(f"{out}/{n}/*/*_counter_collection.csv")
+    if not fs:
+        print(n, "no data"); continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[0])):
+        if "k_update" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    print(n, {k: round(sum(v) / len(v) / 1e6, 2) for k, v in sorted(acc.items())})
+PY
