@@ -323,6 +323,9 @@ PM_DEV void load_ref_tile(const ProblemDev& P, float* tile, int x0, int y0, int 
 // image with pitch `tpitch` whose window taps are all addressable: the block's LDS
 // tile, or (when the tile would not leave room for two blocks per CU) the
 // apron-padded image in global memory.
+// SCALE24: the records are stored times 2^24 (exact), for the 8-bit texture path whose taps come out times 2^-24 (see
+// BilinearTap<true>::value)
+template <bool SCALE24>
 PM_DEV void ref_window(float4* lw, const float* ctr, int tpitch, int step, int radius, float two_ss, float two_sc, RefWin& rw) {
     const float rc = ctr[0];
     float sw = 0.0f, swr = 0.0f, swrr = 0.0f;
@@ -345,7 +348,10 @@ PM_DEV void ref_window(float4* lw, const float* ctr, int tpitch, int step, int r
             pwrr = __builtin_fmaf(wr, r, pwrr);
         }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) lw[(a * 3 + j) * kBlockThreads] = make_float4(wv[2 * j], wv[2 * j + 1], wrv[2 * j], wrv[2 * j + 1]);
+        for (int j = 0; j < 3; ++j) {
+            constexpr float k = SCALE24 ? 16777216.0f : 1.0f;
+            lw[(a * 3 + j) * kBlockThreads] = make_float4(wv[2 * j] * k, wv[2 * j + 1] * k, wrv[2 * j] * k, wrv[2 * j + 1] * k);
+        }
         sw += pw;
         swr += pwr;
         swrr += pwrr;
@@ -453,6 +459,12 @@ PM_DEV SrcTex8 make_src_tex8(const ViewDev& vw) {
 // in flight at once.
 template <bool U8>
 struct BilinearTap;
+#ifndef PM_U8_HALF_TRICK
+#define PM_U8_HALF_TRICK 1
+#endif
+// are the taps of this texture format scaled by 2^-24 (and the weight records by 2^24)?
+template <bool U8>
+constexpr bool kTapScale24 = U8 && (PM_U8_HALF_TRICK != 0);
 
 typedef float f32x4q __attribute__((ext_vector_type(4)));
 template <>
@@ -485,6 +497,27 @@ struct BilinearTap<true> {
         const int off = texel_offset(floor_to_int(cy), floor_to_int(cx), t.pitch);
         q = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(t.rsrc, off, 0, 0);
     }
+#if PM_U8_HALF_TRICK
+    // A byte n in a 16-bit lane IS the fp16 subnormal n * 2^-24.  So the four texels never pass through v_cvt_f32_ubyte:
+    // two bit operations spread them into the half2 registers (t00, t01) and (t10, t11), one packed fp16 subtraction gives
+    // both horizontal differences (exact: integers below 2^11 in units of 2^-24), and the two horizontal interpolations
+    // read their fp16 operands directly (v_fma_mix_f32).  Every value is 2^-24 times the one the fp32 formulation computes,
+    // rounding included (a power-of-two scaling commutes with rounding as long as nothing underflows), and the weight
+    // records are stored times 2^24, so w * s, (w r) * s are the identical floats and sum(w s^2) comes out times 2^-24,
+    // undone once per evaluation.  7 issue slots per tap instead of 10.
+    PM_DEV float value() const {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 A = __builtin_bit_cast(h2, q & 0x00FF00FFu);                              // (t00, t01)
+        const h2 B = __builtin_bit_cast(h2, __builtin_amdgcn_perm(0u, q, 0x0C030C01u));     // (t10, t11)
+        const h2 D = B - A;
+        // fma(ax, (float)D.lo, (float)A.lo) and the same on the high halves, without separate conversions (hipcc does not
+        // form v_fma_mix_f32 from the fpext + fma pattern here)
+        float top, bot;
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(top) : "v"(ax), "v"(D), "v"(A));
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[0,1,1]" : "=v"(bot) : "v"(ax), "v"(D), "v"(A));
+        return __builtin_fmaf(ay, bot - top, top);
+    }
+#else
     PM_DEV float value() const {
         const float t00 = ubyte_to_float<0>(q), t10 = ubyte_to_float<1>(q);
         const float t01 = ubyte_to_float<2>(q), t11 = ubyte_to_float<3>(q);
@@ -492,6 +525,7 @@ struct BilinearTap<true> {
         const float bot = __builtin_fmaf(ax, t11 - t01, t01);
         return __builtin_fmaf(ay, bot - top, top);
     }
+#endif
 };
 
 // plane -> m = (n^T K_r^-1) / d, shared by all views of one hypothesis
@@ -644,6 +678,7 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int s
         }
         consume_column(wB, tapB);
     }
+    if (kTapScale24<U8>) T2 *= 16777216.0f;  // sum(w s^2) was accumulated times 2^-24 (exact)
     const float ms = T1 * rw.inv_w, mss = T2 * rw.inv_w, mrs = T3 * rw.inv_w;
     const float var_s = __builtin_fmaf(-ms, ms, mss);
     if (rw.var_r < 1e-5f || var_s < 1e-5f) return 2.0f;  // ref .cu:406-408

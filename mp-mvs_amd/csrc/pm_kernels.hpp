@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_init(const ProblemDe
     const int V = P.V;
     Rng g = rng_make(a.seed, (uint32_t)idx, a.launch);
     RefWin rw;
-    ref_window((float4*)pm_lds + threadIdx.x, ctr, tpitch, step, radius, a.two_ss, a.two_sc, rw);
+    ref_window<kTapScale24<U8>>((float4*)pm_lds + threadIdx.x, ctr, tpitch, step, radius, a.two_ss, a.two_sc, rw);
 
     float4 pl;
     if (a.init_random) {
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
     const int idx = y * W + x;
     Rng g = rng_make(a.seed, (uint32_t)idx, a.launch);
     RefWin rw;
-    ref_window((float4*)pm_lds + threadIdx.x, ctr, tpitch, step, radius, a.two_ss, a.two_sc, rw);
+    ref_window<kTapScale24<U8>>((float4*)pm_lds + threadIdx.x, ctr, tpitch, step, radius, a.two_ss, a.two_sc, rw);
 
     // -- 8 sampling regions: position of the lowest stored cost (ref .cu:798-816)
     int pos[8];
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_eval_ncc(const Probl
     if (!valid) return;
     const int idx = y * P.W + x;
     RefWin rw;
-    ref_window((float4*)pm_lds + threadIdx.x, ctr, tpitch, step, radius, a.two_ss, a.two_sc, rw);
+    ref_window<kTapScale24<U8>>((float4*)pm_lds + threadIdx.x, ctr, tpitch, step, radius, a.two_ss, a.two_sc, rw);
     float m0, m1, m2;
     plane_to_m(P, planes[idx], m0, m1, m2);
     const long wh = (long)P.W * P.H;

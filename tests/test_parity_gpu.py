@@ -492,3 +492,30 @@ def test_max_image_size_bit_exact(pm, oracle, engine):
     cp, cc = cpu.get()
     assert np.array_equal(gp, cp) and np.array_equal(gc, cc)
     assert np.array_equal(gpu.get_selected_views(), cpu.get_selected_views())
+
+
+def test_near_black_images_bit_exact(pm, oracle, engine):
+    """the 8-bit texture path interpolates in units of 2^-24 (fp16 subnormal trick, BilinearTap<true>::value) and accumulates
+    sum(w s^2) times 2^-24: images of zeros with a few ones and twos put the smallest possible interpolated values through it
+    (underflow would show as a cost difference); NCC on random planes and a whole Run(), HIP == oracle"""
+    rng = np.random.default_rng(5)
+    sc = pm.synth.make_problem_scene(72, 56, n_src=3, spacing=0.4, quantize=True)
+    cams, imgs = sc.problem(0, [1, 2, 3])
+    imgs = [np.where(rng.random(im.shape) < 0.03, rng.integers(1, 3, im.shape), 0).astype(np.float32) for im in imgs]
+    imgs[0][20:40, 20:50] = rng.integers(0, 256, (20, 30))                      # some texture in the reference so that var_r passes
+    imgs[1][15:45, 10:60] += (rng.random((30, 50)) < 0.3) * 1.0
+    dmin, dmax = pm.synth.kernel_depth_range(cams[0])
+    p = pm.PatchMatchParams(num_images=4, depth_min=float(dmin), depth_max=float(dmax), max_scale=2, max_iterations=2)
+    gpu, cpu = engine.create(0), oracle.create()
+    n = rng.normal(size=(56, 72, 3))
+    n[..., 2] = -np.abs(n[..., 2]) - 0.3
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    planes = np.concatenate([n, rng.uniform(3.0, 8.0, (56, 72, 1))], -1).astype(np.float32)
+    for h in (gpu, cpu):
+        h.set_views(cams, imgs)
+    assert gpu.texture_format() == "u8"
+    for scale in (0, 1, 2):
+        assert np.array_equal(gpu.eval_ncc(p, planes, scale), cpu.eval_ncc(p, planes, scale)), f"scale {scale}"
+    for h in (gpu, cpu):
+        h.run(p, 9)
+    assert all(np.array_equal(a, b) for a, b in zip(gpu.get(), cpu.get()))
