@@ -562,19 +562,26 @@ static hipEvent_t get_event(mpmvs_ctx* c) {
     return e;
 }
 
+template <bool U8>
+static dim3 checker_grid(const mpmvs_ctx* c, const LaunchArgs& a) {
+    const int rows = c->H < a.ylimit ? c->H : a.ylimit;
+    return dim3(((c->W + kChkBlockW<U8> - 1) / kChkBlockW<U8>) * ((rows + kChkBlockH<U8> - 1) / kChkBlockH<U8>));
+}
 template <bool GEOM, bool PRIOR, bool U8>
-static void launch_update2(mpmvs_ctx* c, dim3 grid, const LaunchArgs& a) {
+static void launch_update2(mpmvs_ctx* c, const LaunchArgs& a) {
+    const dim3 grid = checker_grid<U8>(c, a);
+    const size_t lds = ncc_lds_bytes(kChkBlockW<U8>, kChkBlockH<U8>, a.scale);
     if (c->hP.V <= 8)
-        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 8, U8>), grid, dim3(256), ncc_lds_bytes(kChkBlockW, kChkBlockH, a.scale), c->stream, c->dP, c->S, a);
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 8, U8>), grid, dim3(256), lds, c->stream, c->dP, c->S, a);
     else
-        hipLaunchKernelGGL((k_update<GEOM, PRIOR, kMaxViews, U8>), grid, dim3(256), ncc_lds_bytes(kChkBlockW, kChkBlockH, a.scale), c->stream, c->dP, c->S, a);
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, kMaxViews, U8>), grid, dim3(256), lds, c->stream, c->dP, c->S, a);
 }
 template <bool GEOM, bool PRIOR>
-static void launch_update(mpmvs_ctx* c, dim3 grid, const LaunchArgs& a) {
+static void launch_update(mpmvs_ctx* c, const LaunchArgs& a) {
     if (c->all_u8)
-        launch_update2<GEOM, PRIOR, true>(c, grid, a);
+        launch_update2<GEOM, PRIOR, true>(c, a);
     else
-        launch_update2<GEOM, PRIOR, false>(c, grid, a);
+        launch_update2<GEOM, PRIOR, false>(c, a);
 }
 
 static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int kind, int iter, int scale, uint32_t launch) {
@@ -602,8 +609,7 @@ static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int 
     }
     const dim3 blk(256);
     const dim3 grid_dense((c->W + 15) / 16, (c->H + 15) / 16);
-    const int rows = c->H < a.ylimit ? c->H : a.ylimit;
-    const dim3 grid_chk(((c->W + kChkBlockW - 1) / kChkBlockW) * ((rows + kChkBlockH - 1) / kChkBlockH));
+    const dim3 grid_chk = checker_grid<true>(c, a);  // k_filter (checker_pixel<true>)
     switch (kind) {
         case MPMVS_KIND_INIT:
             if (c->hP.V <= 8 && c->all_u8)
@@ -618,13 +624,13 @@ static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int 
         case MPMVS_KIND_BLACK:
         case MPMVS_KIND_RED:
             if (p->geom_consistency && p->planar_prior)
-                launch_update<true, true>(c, grid_chk, a);
+                launch_update<true, true>(c, a);
             else if (p->geom_consistency)
-                launch_update<true, false>(c, grid_chk, a);
+                launch_update<true, false>(c, a);
             else if (p->planar_prior)
-                launch_update<false, true>(c, grid_chk, a);
+                launch_update<false, true>(c, a);
             else
-                launch_update<false, false>(c, grid_chk, a);
+                launch_update<false, false>(c, a);
             break;
         case MPMVS_KIND_DEPTH_NORMAL:
             hipLaunchKernelGGL(k_depth_normal, grid_dense, blk, 0, c->stream, c->dP, c->S);

@@ -53,12 +53,20 @@ __device__ constexpr int kNumDirs[8] = {12, 12, 12, 12, 10, 10, 10, 10};
 // Measured (update launch, cfg 1).  Early kernel (gathers serialised): 8 rows (16x8 px patch) 8.13 ms, 4 rows 8.45,
 // 2 rows 8.59, 1 row 8.87 -- compact 2-D patches reuse more L1 lines between taps.  Final kernel (LDS weights, pipelined
 // gathers): 4 rows (32x4 px) 3.853, 8 rows 3.891, 2 rows 3.981, 16 rows 4.835; geometric mode 4.81 vs 5.13.
+// The fp32 texture format (16-byte gathers) prefers the taller patch: 4.70 ms with 8 rows against 4.95 with 4.
 #ifndef PM_WAVE_ROWS
 #define PM_WAVE_ROWS 4
 #endif
-constexpr int kLanesPerRow = 64 / PM_WAVE_ROWS;
-constexpr int kChkBlockW = 2 * kLanesPerRow;   // pixels
-constexpr int kChkBlockH = 4 * PM_WAVE_ROWS;   // pixels
+#ifndef PM_WAVE_ROWS_F32
+#define PM_WAVE_ROWS_F32 8
+#endif
+// rows per wave, block width and height (pixels) of a checkerboard launch on textures of format U8
+template <bool U8>
+constexpr int kWaveRows = U8 ? PM_WAVE_ROWS : PM_WAVE_ROWS_F32;
+template <bool U8>
+constexpr int kChkBlockW = 2 * (64 / kWaveRows<U8>);
+template <bool U8>
+constexpr int kChkBlockH = 4 * kWaveRows<U8>;
 
 // Blocks are dealt round-robin to the 8 XCDs (block b and b+8 share an L2):
 // renumber so that each XCD works through one contiguous run of the raster
@@ -70,14 +78,16 @@ PM_DEV int xcd_remap(int id, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+template <bool U8>
 PM_DEV bool checker_pixel(const ProblemDev& P, const LaunchArgs& a, int& x, int& y, int& x0, int& y0) {
-    const int nbx = (P.W + kChkBlockW - 1) / kChkBlockW;
+    constexpr int kLanesPerRow = 64 / kWaveRows<U8>;
+    const int nbx = (P.W + kChkBlockW<U8> - 1) / kChkBlockW<U8>;
     const int b = xcd_remap(blockIdx.x, gridDim.x);
     const int by = b / nbx, bx = b - by * nbx;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    x0 = bx * kChkBlockW;
-    y0 = by * kChkBlockH;
-    y = y0 + wv * PM_WAVE_ROWS + lane / kLanesPerRow;
+    x0 = bx * kChkBlockW<U8>;
+    y0 = by * kChkBlockH<U8>;
+    y = y0 + wv * kWaveRows<U8> + lane / kLanesPerRow;
     x = x0 + 2 * (lane % kLanesPerRow);
     x += (y + a.parity) & 1;
     return x < P.W && y < P.H && y < a.ylimit;
@@ -207,10 +217,10 @@ template <bool GEOM, bool PRIOR, int MAXV, bool U8>
 __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
     const ProblemDev& P = *Pp;
     int x, y, x0, y0;
-    const bool valid = checker_pixel(P, a, x, y, x0, y0);
+    const bool valid = checker_pixel<U8>(P, a, x, y, x0, y0);
     const int step = 2 << a.scale, radius = 5 * step / 2;
     int tpitch;
-    const float* ctr = ref_center(P, pm_lds + kLdsWeightFloats, x, y, x0, y0, kChkBlockW, kChkBlockH, radius, a.scale, tpitch);
+    const float* ctr = ref_center(P, pm_lds + kLdsWeightFloats, x, y, x0, y0, kChkBlockW<U8>, kChkBlockH<U8>, radius, a.scale, tpitch);
     if (!valid) return;
     const int W = P.W, Hh = P.H, V = P.V;
     const int idx = y * W + x;
@@ -520,7 +530,7 @@ __global__ __launch_bounds__(256) void k_depth_normal(const ProblemDev* __restri
 __global__ __launch_bounds__(256) void k_filter(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
     const ProblemDev& P = *Pp;
     int x, y, x0, y0;
-    if (!checker_pixel(P, a, x, y, x0, y0)) return;
+    if (!checker_pixel<true>(P, a, x, y, x0, y0)) return;  // the filter has no texture: any shape
     const int W = P.W, Hh = P.H;
     const int ctr = y * W + x;
     if (S.costs[ctr] < 0.001f) return;
