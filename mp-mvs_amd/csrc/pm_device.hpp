@@ -612,6 +612,10 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int s
         T1 += A1.x + A1.y;
         T2 += A2.x + A2.y;
         T3 += A3.x + A3.y;
+        // T3 is only consumed after the variance test at the end, so the compiler would SINK its whole accumulation behind that
+        // branch: keep all 36 interpolated values alive in registers (36 VGPRs in a kernel that sits at the 256 cap) and re-read
+        // the weight records from LDS there.  Pin it to the column it belongs to.
+        asm volatile("" : "+v"(T3));
     };
 #else
     auto issue_column = [&](int a, BilinearTap<U8>(&tap)[6]) {
