@@ -687,7 +687,7 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int s
     const float var_s = __builtin_fmaf(-ms, ms, mss);
     if (rw.var_r < 1e-5f || var_s < 1e-5f) return 2.0f;  // ref .cu:406-408
     const float cov = __builtin_fmaf(-rw.mean_r, ms, mrs);
-    const float den = __builtin_sqrtf(rw.var_r * var_s);
+    const float den = d_sqrt_normal(rw.var_r * var_s);  // both factors >= 1e-5: correctly rounded without the range handling of sqrtf
     float cost = 1.0f - cov / den;
     cost = (cost < 2.0f) ? cost : 2.0f;  // ref .cu:412
     cost = (cost > 0.0f) ? cost : 0.0f;

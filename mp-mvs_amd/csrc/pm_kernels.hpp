@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
             if (slot < 8) {
                 cost_arr[slot * MAXV + v] = c;
                 if (c < thr) {
-                    tmpw[v] += d_exp((c * c) / (-0.18f));
+                    tmpw[v] += d_exp_inrange((c * c) / (-0.18f));  // c in [0, 2]: argument in [-22.3, 0]
                     cnt[v] += 1;
                 }
                 if (c > 1.2f) cnt[v] += 256;
