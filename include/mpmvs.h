@@ -120,7 +120,10 @@ int mpmvs_set_prior(mpmvs_ctx* ctx, const void* prior_planes4, const void* mask_
 /* PatchMatchCUDA::Run() (src/PatchMatch.cu:1188-1254) without its final
  * device-to-host copies: InitializeScore, the red/black schedule selected by
  * params, GetDepthandNormal, both filters.  `seed` replaces
- * curand_init(clock64(), ...) (src/PatchMatch.cu:546).  Blocks until done. */
+ * curand_init(clock64(), ...) (src/PatchMatch.cu:546).  Blocks until done.
+ * params->geom_consistency together with params->planar_prior is rejected (-7):
+ * the reference never runs that combination (ProcessProblem clears
+ * geom_consistency before the prior Run(), src/PatchMatch.cpp:535). */
 int mpmvs_run(mpmvs_ctx* ctx, const mpmvs_params* params, uint64_t seed);
 /* one kernel of Run(), for parity tests; launch_id selects the RNG stream the
  * way Run() numbers its launches (0 = InitializeScore, then in launch order) */

@@ -548,6 +548,9 @@ static int check_ready(mpmvs_ctx* c, const mpmvs_params* p) {
     if (p->max_scale < 0 || p->max_scale > 2) return fail(c, -3, "max_scale must be 0..2 (window radius <= 20)");
     if (p->geom_consistency && !c->have_depths) return fail(c, -4, "geom_consistency needs source depth maps");
     if (p->planar_prior && !c->have_prior) return fail(c, -5, "planar_prior needs set_prior");
+    // The reference never runs both at once: ProcessProblem clears geom_consistency before the prior Run()
+    // (ref src/PatchMatch.cpp:535), so that kernel variant is not built.
+    if (p->geom_consistency && p->planar_prior) return fail(c, -7, "geom_consistency and planar_prior are mutually exclusive (ref PatchMatch.cpp:535)");
     return 0;
 }
 
@@ -623,9 +626,7 @@ static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int 
             break;
         case MPMVS_KIND_BLACK:
         case MPMVS_KIND_RED:
-            if (p->geom_consistency && p->planar_prior)
-                launch_update<true, true>(c, a);
-            else if (p->geom_consistency)
+            if (p->geom_consistency)
                 launch_update<true, false>(c, a);
             else if (p->planar_prior)
                 launch_update<false, true>(c, a);

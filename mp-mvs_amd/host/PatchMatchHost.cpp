@@ -388,6 +388,33 @@ int mpmvs_host_build_prior(const mpmvs_camera* cam, int w, int h, const float* p
     return (int)pp.size();
 }
 
+// Raster + plane fit + depth-range test for an EXPLICIT triangle list (tri_xy = n x {x1 y1 x2 y2 x3 y3}, labelled 1..n in
+// the given order; reference src/PatchMatch.cpp:554-595).  plane_out (n x 4, may be NULL) receives the per-triangle planes.
+// Lets the fixtures of tests/golden/prior_golden_v1.npz pin triangle order ("last one wins") and plane fit separately
+// from the Delaunay triangulation.  Returns the number of triangles kept (all vertices inside the image), or -1.
+int mpmvs_host_prior_from_triangles(const mpmvs_camera* cam, int w, int h, const int* tri_xy, int n, const float* planes4, float depth_min,
+                                    float depth_max, float* prior4, uint32_t* mask, float* plane_out) {
+    if (!cam || !tri_xy || n < 0 || !planes4 || !prior4 || !mask) return -1;
+    std::vector<Triangle> tris;
+    tris.reserve(n);
+    for (int i = 0; i < n; ++i)
+        tris.push_back(Triangle(Point(tri_xy[6 * i], tri_xy[6 * i + 1]), Point(tri_xy[6 * i + 2], tri_xy[6 * i + 3]),
+                                Point(tri_xy[6 * i + 4], tri_xy[6 * i + 5])));
+    std::vector<float4> pp;
+    Image m;
+    mpmvs_host::BuildPrior(*cam, w, h, tris, (const float4*)planes4, depth_min, depth_max, pp, m);
+    for (int i = 0; i < h; ++i)
+        for (int j = 0; j < w; ++j) {
+            const size_t idx = (size_t)i * w + j;
+            mask[idx] = (uint32_t)m.at(i, j);
+            float4 o{0, 0, 0, 0};
+            if (m.at(i, j) > 0) o = pp[(size_t)m.at(i, j) - 1];
+            std::memcpy(prior4 + 4 * idx, &o, 16);
+        }
+    if (plane_out) std::memcpy(plane_out, pp.data(), pp.size() * sizeof(float4));
+    return (int)pp.size();
+}
+
 // bilinear resize probe (ResizeLinear)
 int mpmvs_host_resize_linear(const float* src, int w, int h, float* dst, int new_w, int new_h) {
     Image s(h, w, 1);

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "host", "libmpmvs_host.so")
 SYMBOLS = ["mpmvs_host_triangulate_vertices", "mpmvs_host_delaunay", "mpmvs_host_build_prior", "mpmvs_host_run_pipeline",
            "mpmvs_host_write_dmb", "mpmvs_host_read_dmb", "mpmvs_host_read_camera", "mpmvs_host_sample_list", "mpmvs_host_read_pgm",
            "mpmvs_host_run_folder", "mpmvs_host_resize_linear", "mpmvs_host_write_ply", "mpmvs_host_fuse_folder", "mpmvs_host_read_image",
-           "mpmvs_host_decode_jpeg", "mpmvs_host_refine_sky_masks", "mpmvs_host_run_folder_jacobi"]
+           "mpmvs_host_decode_jpeg", "mpmvs_host_refine_sky_masks", "mpmvs_host_run_folder_jacobi", "mpmvs_host_prior_from_triangles"]
 _cache = {}
 
 
@@ -29,6 +29,8 @@ def load():
         lib.mpmvs_host_delaunay.argtypes = [C.c_int, C.c_int, P, C.c_int, P, C.c_int]
         lib.mpmvs_host_build_prior.restype = C.c_int
         lib.mpmvs_host_build_prior.argtypes = [C.POINTER(_abi.Camera), C.c_int, C.c_int, P, P, P, C.c_int, C.c_float, C.c_float, P, P]
+        lib.mpmvs_host_prior_from_triangles.restype = C.c_int
+        lib.mpmvs_host_prior_from_triangles.argtypes = [C.POINTER(_abi.Camera), C.c_int, C.c_int, P, C.c_int, P, C.c_float, C.c_float, P, P, P]
         lib.mpmvs_host_run_pipeline.restype = C.c_int
         lib.mpmvs_host_run_pipeline.argtypes = [C.c_int, C.c_int, C.POINTER(_abi.Camera), C.POINTER(C.POINTER(C.c_float)), C.c_int, C.c_int,
                                                 C.c_int, C.c_int, C.c_uint64, C.POINTER(C.POINTER(C.c_float)), P, P, P, C.c_int]
@@ -96,6 +98,23 @@ def build_prior(cam, planes, costs, geom_costs, geom_planar_prior, depth_min, de
     n = lib.mpmvs_host_build_prior(C.byref(cam), w, h, planes.ctypes.data, costs.ctypes.data, g.ctypes.data if g is not None else None,
                                    1 if geom_planar_prior else 0, float(depth_min), float(depth_max), prior.ctypes.data, mask.ctypes.data)
     return prior, mask, n
+
+
+def prior_from_triangles(cam, tri_pts, planes, depth_min, depth_max):
+    """raster + plane fit + depth-range test for an explicit triangle list [n][3][2] (labels 1..n in that order):
+    (prior planes HxWx4, mask HxW u32, per-triangle planes nx4)"""
+    lib = load()
+    planes = np.ascontiguousarray(planes, np.float32)
+    h, w = planes.shape[:2]
+    t = np.ascontiguousarray(tri_pts, np.int32).reshape(-1, 6)
+    prior = np.zeros((h, w, 4), np.float32)
+    mask = np.zeros((h, w), np.uint32)
+    pl = np.zeros((len(t), 4), np.float32)
+    n = lib.mpmvs_host_prior_from_triangles(C.byref(cam), w, h, t.ctypes.data, len(t), planes.ctypes.data, float(depth_min), float(depth_max),
+                                            prior.ctypes.data, mask.ctypes.data, pl.ctypes.data)
+    if n < 0:
+        raise RuntimeError("prior_from_triangles failed")
+    return prior, mask, pl[:n]
 
 
 def run_pipeline(device, cams, images, max_scale, geom_iterations, planar_prior, geom_planar_prior, seed, src_depths=None, max_image_size=0, out_size=None):

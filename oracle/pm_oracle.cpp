@@ -1026,6 +1026,8 @@ int check_ready(Ctx& c, const Params& p) {
     if (p.num_images - 1 > kMaxViews) { c.err = "too many source views"; return -3; }
     if (p.geom_consistency && (int)c.depths.size() != c.n_img - 1) { c.err = "geom_consistency needs source depth maps"; return -4; }
     if (p.planar_prior && !c.have_prior) { c.err = "planar_prior needs set_prior"; return -5; }
+    // never reached by the reference (ref src/PatchMatch.cpp:535 clears geom_consistency before the prior Run())
+    if (p.geom_consistency && p.planar_prior) { c.err = "geom_consistency and planar_prior are mutually exclusive"; return -7; }
     return 0;
 }
 
