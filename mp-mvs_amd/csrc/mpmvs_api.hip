@@ -32,6 +32,7 @@
 #include "pm_fusion.hpp"
 #include "pm_sky.hpp"
 #include "pm_kernels.hpp"
+#include "pm_coop.hpp"
 
 using namespace pm;
 
@@ -46,8 +47,11 @@ struct mpmvs_ctx {
     ProblemDev hP;               // host mirror
     ProblemDev* dP = nullptr;    // device copy
     float* d_ref = nullptr;
-    std::vector<float*> d_src;   // padded source images (fp32 format)
-    std::vector<uint32_t*> d_src8;  // quad-packed u8 source textures (when every image is 8-bit exact)
+    // the quad-packed source textures of all views live in ONE allocation (a single buffer resource can then address
+    // every view: the cooperative kernels sample a different view per lane); d_src / d_src8 point into it
+    void* d_tex_all = nullptr;
+    std::vector<float*> d_src;      // fp32 format: w x h float4 texels per view
+    std::vector<uint32_t*> d_src8;  // u8 format (every image 8-bit exact): w x h dwords per view
     bool all_u8 = false;
     std::vector<float*> d_depth; // dense source depth maps
     StateDev S{};
@@ -167,13 +171,24 @@ static hipError_t pool_free(void* p) {
     return hipFree(p);
 }
 
+// scratch device buffer of a probe call: released on every return path (hipFree waits for the device)
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4); }
+    template <typename T>
+    T* as() const { return (T*)p; }
+};
+
 static void free_views(mpmvs_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);  // nothing may still use what goes back to the pool
     if (c->d_ref) (void)pool_free(c->d_ref);
     c->d_ref = nullptr;
-    for (float* p : c->d_src) (void)pool_free(p);
+    if (c->d_tex_all) (void)pool_free(c->d_tex_all);
+    c->d_tex_all = nullptr;
     c->d_src.clear();
-    for (uint32_t* p : c->d_src8) (void)pool_free(p);
     c->d_src8.clear();
     c->all_u8 = false;
     for (float* p : c->d_depth) (void)pool_free(p);
@@ -257,41 +272,47 @@ static int upload_problem(mpmvs_ctx* c) {
 static int upload_padded(mpmvs_ctx* c, const float* host, size_t pitch, int w, int h, int apron, float** out) {
     float* d_raw = nullptr;
     HIPCHK(c, pool_malloc(&d_raw, (size_t)w * h * 4));
-    HIPCHK(c, hipMemcpy2DAsync(d_raw, (size_t)w * 4, host, pitch, (size_t)w * 4, h, hipMemcpyHostToDevice, c->stream));
     const int pw = w + 2 * apron, ph = h + 2 * apron;
     float* d_pad = nullptr;
-    HIPCHK(c, pool_malloc(&d_pad, (size_t)pw * ph * 4));
-    hipLaunchKernelGGL(k_pad, dim3((pw + 255) / 256, ph), dim3(256), 0, c->stream, d_raw, w, h, d_pad, apron);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, pool_free(d_raw));
+    int rc = 0;
+    if (pool_malloc(&d_pad, (size_t)pw * ph * 4) != hipSuccess) rc = -100;
+    if (!rc && hipMemcpy2DAsync(d_raw, (size_t)w * 4, host, pitch, (size_t)w * 4, h, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = -100;
+    if (!rc) {
+        hipLaunchKernelGGL(k_pad, dim3((pw + 255) / 256, ph), dim3(256), 0, c->stream, d_raw, w, h, d_pad, apron);
+        if (hipGetLastError() != hipSuccess) rc = -100;
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = -100;  // also on failure: nothing may still use what goes back to the pool
+    (void)pool_free(d_raw);
+    if (rc) {
+        (void)pool_free(d_pad);
+        c->err = "upload of the reference image failed";
+        return rc;
+    }
     *out = d_pad;
     return 0;
 }
 
-// host image -> dense staging buffer -> quad-packed fp32 texture (w x h float4)
-static int upload_extended(mpmvs_ctx* c, const float* host, size_t pitch, int w, int h, float** out) {
+// host image -> dense staging buffer -> quad-packed fp32 texture (w x h float4) at d_e
+static int upload_extended(mpmvs_ctx* c, const float* host, size_t pitch, int w, int h, float* d_e) {
     float* d_raw = nullptr;
     HIPCHK(c, pool_malloc(&d_raw, (size_t)w * h * 4));
-    HIPCHK(c, hipMemcpy2DAsync(d_raw, (size_t)w * 4, host, pitch, (size_t)w * 4, h, hipMemcpyHostToDevice, c->stream));
-    float* d_e = nullptr;
-    HIPCHK(c, pool_malloc(&d_e, (size_t)w * h * 16));
-    hipLaunchKernelGGL(k_pack_quads_f32, dim3((w + 255) / 256, h), dim3(256), 0, c->stream, d_raw, w, h, (float4*)d_e);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, pool_free(d_raw));
-    *out = d_e;
-    return 0;
+    int rc = 0;
+    if (hipMemcpy2DAsync(d_raw, (size_t)w * 4, host, pitch, (size_t)w * 4, h, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = -100;
+    if (!rc) {
+        hipLaunchKernelGGL(k_pack_quads_f32, dim3((w + 255) / 256, h), dim3(256), 0, c->stream, d_raw, w, h, (float4*)d_e);
+        if (hipGetLastError() != hipSuccess) rc = -100;
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = -100;  // also on failure: the staging buffer goes back to the pool
+    (void)pool_free(d_raw);
+    if (rc) c->err = "upload of a source image failed";
+    return rc;
 }
 
-// 8-bit host image -> (shared staging buffer) -> quad-packed u8 texture.  Stream ordered: the staging buffer may be
+// 8-bit host image -> (shared staging buffer) -> quad-packed u8 texture at d_q.  Stream ordered: the staging buffer may be
 // overwritten by the next view's copy once this pack kernel has been enqueued.
-static int upload_quads_u8(mpmvs_ctx* c, const unsigned char* host8, unsigned char* d_stage, int w, int h, uint32_t** out) {
+static int upload_quads_u8(mpmvs_ctx* c, const unsigned char* host8, unsigned char* d_stage, int w, int h, uint32_t* d_q) {
     HIPCHK(c, hipMemcpyAsync(d_stage, host8, (size_t)w * h, hipMemcpyHostToDevice, c->stream));
-    uint32_t* d_q = nullptr;
-    HIPCHK(c, pool_malloc(&d_q, (size_t)w * h * 4));
-    *out = d_q;  // owned by the context from here on (freed by free_views also on a later error)
-    hipLaunchKernelGGL(k_pack_quads_u8, dim3((w + 255) / 256, h), dim3(256), 0, c->stream, d_stage, w, h, d_q);
+    hipLaunchKernelGGL(k_pack_quads_u8, dim3((w + 255) / 256, h), dim3(256), 0, c->stream, d_stage, w, h, (uint2*)d_q);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -417,6 +438,18 @@ int mpmvs_set_views(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* 
     std::vector<std::vector<unsigned char>> src8;
     bool exact = !c->force_f32 && convert_sources_u8(n, cams, images, pitch_bytes, src8);
     c->all_u8 = exact;
+    // one allocation for the textures of all views, each 256-byte aligned; a buffer resource addresses 32-bit offsets
+    const size_t texel = exact ? 8 : 16;
+    std::vector<size_t> tex_off(n, 0);
+    size_t tex_total = 0;
+    for (int v = 1; v < n; ++v) {
+        tex_off[v] = tex_total;
+        tex_total += ((size_t)cams[v].width * cams[v].height * texel + 255) & ~(size_t)255;
+    }
+    if (tex_total >= (1ull << 32)) return fail(c, -3, "source textures exceed 4 GB in total");
+    HIPCHK(c, pool_malloc(&c->d_tex_all, tex_total));
+    c->hP.tex_all = c->d_tex_all;
+    c->hP.tex_all_bytes = (uint32_t)tex_total;
     if (exact) c->d_src8.assign(n - 1, nullptr); else c->d_src.assign(n - 1, nullptr);
     unsigned char* d_stage = nullptr;
     if (exact) {
@@ -428,8 +461,10 @@ int mpmvs_set_views(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* 
         const int w = cams[v].width, h = cams[v].height;
         const size_t pitch = pitch_bytes ? pitch_bytes[v] : (size_t)w * 4;
         ViewDev& o = c->hP.views[v - 1];
+        o.tex_base = (uint32_t)tex_off[v];
         if (exact) {
-            if ((rc = upload_quads_u8(c, src8[v - 1].data(), d_stage, w, h, &c->d_src8[v - 1]))) {
+            c->d_src8[v - 1] = (uint32_t*)((char*)c->d_tex_all + tex_off[v]);
+            if ((rc = upload_quads_u8(c, src8[v - 1].data(), d_stage, w, h, c->d_src8[v - 1]))) {
                 (void)hipStreamSynchronize(c->stream);
                 (void)pool_free(d_stage);
                 return rc;
@@ -437,7 +472,8 @@ int mpmvs_set_views(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* 
             o.pitch8 = w;
             o.img8 = c->d_src8[v - 1];
         } else {
-            if ((rc = upload_extended(c, images[v], pitch, w, h, &c->d_src[v - 1]))) return rc;
+            c->d_src[v - 1] = (float*)((char*)c->d_tex_all + tex_off[v]);
+            if ((rc = upload_extended(c, images[v], pitch, w, h, c->d_src[v - 1]))) return rc;
             o.pitch = w;
             o.img = c->d_src[v - 1];
         }
@@ -737,38 +773,77 @@ int mpmvs_export_depth_device(mpmvs_ctx* c, float* d_out) {
     return 0;
 }
 
-int mpmvs_eval_ncc(mpmvs_ctx* c, const mpmvs_params* p, const void* planes_cam4, int scale, void* out) {
+// mapping: 0 = one thread per pixel (k_eval_ncc), 1/2 = cooperative groups of 4 lanes per pixel compiled for 4 / 3 waves
+// per SIMD, 3/4 = groups of 8 lanes, 4 / 3 waves per SIMD (pm_coop.hpp)
+static int eval_ncc_impl(mpmvs_ctx* c, const mpmvs_params* p, const void* planes_cam4, int nh, int scale, int mapping, void* out, float* kernel_ms) {
     if (!c || !p) return -1;
     HIPCHK(c, enter_device(c->device));
     int rc = check_ready(c, p);
     if (rc) return rc;
     if (scale < 0 || scale > 2) return fail(c, -3, "scale must be 0..2");
+    if (nh < 1 || mapping < 0 || mapping > 4) return fail(c, -3, "bad probe arguments");
     const size_t wh = (size_t)c->W * c->H;
     const int V = c->hP.V;
-    float4* d_pl = nullptr;
-    float* d_out = nullptr;
-    HIPCHK(c, hipMalloc(&d_pl, wh * 16));
-    HIPCHK(c, hipMalloc(&d_out, wh * 4 * V));
-    HIPCHK(c, hipMemcpyAsync(d_pl, planes_cam4, wh * 16, hipMemcpyHostToDevice, c->stream));
+    DevBuf d_pl, d_out;
+    HIPCHK(c, d_pl.alloc(wh * 16 * nh));
+    HIPCHK(c, d_out.alloc(wh * 4 * V * nh));
+    HIPCHK(c, hipMemcpyAsync(d_pl.p, planes_cam4, wh * 16 * nh, hipMemcpyHostToDevice, c->stream));
     LaunchArgs a{};
     a.scale = scale;
     a.two_ss = (2.0f * p->sigma_spatial) * p->sigma_spatial;
     a.two_sc = (2.0f * p->sigma_color) * p->sigma_color;
-    const dim3 grid((c->W + 15) / 16, (c->H + 15) / 16);
-    if (V <= 8 && c->all_u8)
-        hipLaunchKernelGGL((k_eval_ncc<8, true>), grid, dim3(256), ncc_lds_bytes(16, 16, scale), c->stream, c->dP, d_pl, d_out, a);
-    else if (V <= 8)
-        hipLaunchKernelGGL((k_eval_ncc<8, false>), grid, dim3(256), ncc_lds_bytes(16, 16, scale), c->stream, c->dP, d_pl, d_out, a);
-    else if (c->all_u8)
-        hipLaunchKernelGGL((k_eval_ncc<kMaxViews, true>), grid, dim3(256), ncc_lds_bytes(16, 16, scale), c->stream, c->dP, d_pl, d_out, a);
-    else
-        hipLaunchKernelGGL((k_eval_ncc<kMaxViews, false>), grid, dim3(256), ncc_lds_bytes(16, 16, scale), c->stream, c->dP, d_pl, d_out, a);
+    hipEvent_t e0 = get_event(c), e1 = get_event(c);
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    const int radius = 5 * (2 << scale) / 2;
+    if (mapping == 0) {
+        const dim3 grid((c->W + 15) / 16, (c->H + 15) / 16);
+        const size_t lds = ncc_lds_bytes(16, 16, scale);
+        if (V <= 8 && c->all_u8)
+            hipLaunchKernelGGL((k_eval_ncc<8, true>), grid, dim3(256), lds, c->stream, c->dP, d_pl.as<float4>(), nh, d_out.as<float>(), a);
+        else if (V <= 8)
+            hipLaunchKernelGGL((k_eval_ncc<8, false>), grid, dim3(256), lds, c->stream, c->dP, d_pl.as<float4>(), nh, d_out.as<float>(), a);
+        else if (c->all_u8)
+            hipLaunchKernelGGL((k_eval_ncc<kMaxViews, true>), grid, dim3(256), lds, c->stream, c->dP, d_pl.as<float4>(), nh, d_out.as<float>(), a);
+        else
+            hipLaunchKernelGGL((k_eval_ncc<kMaxViews, false>), grid, dim3(256), lds, c->stream, c->dP, d_pl.as<float4>(), nh, d_out.as<float>(), a);
+    } else {
+        const int G = mapping <= 2 ? 4 : 8, pix = 256 / G, bh = pix / 8;
+        const dim3 grid((c->W + 7) / 8, (c->H + bh - 1) / bh);
+        const int fixed = G == 4 ? kCoopFixedFloats<4> : kCoopFixedFloats<8>;
+        const size_t lds = (size_t)(fixed + (use_ref_tile(scale) ? (8 + 2 * radius) * (bh + 2 * radius) : 0)) * sizeof(float);
+#define PM_LAUNCH_COOP(U8, G_, WV) \
+    hipLaunchKernelGGL((k_eval_ncc_coop<U8, G_, WV>), grid, dim3(256), lds, c->stream, c->dP, d_pl.as<float4>(), nh, d_out.as<float>(), a)
+        if (c->all_u8) {
+            if (mapping == 1) PM_LAUNCH_COOP(true, 4, 4);
+            if (mapping == 2) PM_LAUNCH_COOP(true, 4, 3);
+            if (mapping == 3) PM_LAUNCH_COOP(true, 8, 4);
+            if (mapping == 4) PM_LAUNCH_COOP(true, 8, 3);
+        } else {
+            if (mapping == 1) PM_LAUNCH_COOP(false, 4, 4);
+            if (mapping == 2) PM_LAUNCH_COOP(false, 4, 3);
+            if (mapping == 3) PM_LAUNCH_COOP(false, 8, 4);
+            if (mapping == 4) PM_LAUNCH_COOP(false, 8, 3);
+        }
+#undef PM_LAUNCH_COOP
+    }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(out, d_out, wh * 4 * V, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, d_out.p, wh * 4 * V * nh, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipFree(d_pl));
-    HIPCHK(c, hipFree(d_out));
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (kernel_ms) *kernel_ms = ms;
+    c->event_pool.push_back(e0);
+    c->event_pool.push_back(e1);
     return 0;
+}
+
+int mpmvs_eval_ncc(mpmvs_ctx* c, const mpmvs_params* p, const void* planes_cam4, int scale, void* out) {
+    return eval_ncc_impl(c, p, planes_cam4, 1, scale, 0, out, nullptr);
+}
+
+int mpmvs_eval_ncc_multi(mpmvs_ctx* c, const mpmvs_params* p, const void* planes_cam4, int nh, int scale, int mapping, void* out, float* kernel_ms) {
+    return eval_ncc_impl(c, p, planes_cam4, nh, scale, mapping, out, kernel_ms);
 }
 
 int mpmvs_eval_geom(mpmvs_ctx* c, const mpmvs_params* p, const void* planes_cam4, void* out) {
@@ -778,18 +853,15 @@ int mpmvs_eval_geom(mpmvs_ctx* c, const mpmvs_params* p, const void* planes_cam4
     if (!c->have_depths) return fail(c, -4, "need source depth maps");
     const size_t wh = (size_t)c->W * c->H;
     const int V = c->hP.V;
-    float4* d_pl = nullptr;
-    float* d_out = nullptr;
-    HIPCHK(c, hipMalloc(&d_pl, wh * 16));
-    HIPCHK(c, hipMalloc(&d_out, wh * 4 * V));
-    HIPCHK(c, hipMemcpyAsync(d_pl, planes_cam4, wh * 16, hipMemcpyHostToDevice, c->stream));
+    DevBuf d_pl, d_out;
+    HIPCHK(c, d_pl.alloc(wh * 16));
+    HIPCHK(c, d_out.alloc(wh * 4 * V));
+    HIPCHK(c, hipMemcpyAsync(d_pl.p, planes_cam4, wh * 16, hipMemcpyHostToDevice, c->stream));
     const dim3 grid((c->W + 15) / 16, (c->H + 15) / 16);
-    hipLaunchKernelGGL(k_eval_geom, grid, dim3(256), 0, c->stream, c->dP, d_pl, d_out);
+    hipLaunchKernelGGL(k_eval_geom, grid, dim3(256), 0, c->stream, c->dP, d_pl.as<float4>(), d_out.as<float>());
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(out, d_out, wh * 4 * V, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, d_out.p, wh * 4 * V, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipFree(d_pl));
-    HIPCHK(c, hipFree(d_out));
     return 0;
 }
 
@@ -797,14 +869,13 @@ int mpmvs_homography(mpmvs_ctx* c, const void* plane4, int v, void* H9) {
     if (!c) return -1;
     HIPCHK(c, enter_device(c->device));
     if (c->n_img < 2 || v < 0 || v >= c->hP.V) return fail(c, -1, "bad source view");
-    float* d_h = nullptr;
-    HIPCHK(c, hipMalloc(&d_h, 9 * 4));
+    DevBuf d_h;
+    HIPCHK(c, d_h.alloc(9 * 4));
     const float* pf = (const float*)plane4;
-    hipLaunchKernelGGL(k_homography, dim3(1), dim3(64), 0, c->stream, c->dP, make_float4(pf[0], pf[1], pf[2], pf[3]), v, d_h);
+    hipLaunchKernelGGL(k_homography, dim3(1), dim3(64), 0, c->stream, c->dP, make_float4(pf[0], pf[1], pf[2], pf[3]), v, d_h.as<float>());
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(H9, d_h, 9 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(H9, d_h.p, 9 * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipFree(d_h));
     return 0;
 }
 

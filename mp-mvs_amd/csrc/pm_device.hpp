@@ -43,6 +43,7 @@ struct ViewDev {
     const float* depth;  // dense source depth map (geometric consistency) or null
     int dw, dh;
     float dwm1, dhm1;
+    uint32_t tex_base;  // byte offset of this view's texture inside ProblemDev::tex_all
     CamDev cam;
 };
 
@@ -54,6 +55,8 @@ struct ProblemDev {
     int W, H, V;
     const float* ref_img;  // texel (0,0) of the reference image, apron kRefApron
     int ref_pitch;
+    const void* tex_all;     // the one allocation holding the quad-packed textures of all source views
+    uint32_t tex_all_bytes;
     ViewDev views[kMaxViews];
 };
 
@@ -323,9 +326,6 @@ PM_DEV void load_ref_tile(const ProblemDev& P, float* tile, int x0, int y0, int 
 // image with pitch `tpitch` whose window taps are all addressable: the block's LDS
 // tile, or (when the tile would not leave room for two blocks per CU) the
 // apron-padded image in global memory.
-// SCALE24: the records are stored times 2^24 (exact), for the 8-bit texture path whose taps come out times 2^-24 (see
-// BilinearTap<true>::value)
-template <bool SCALE24>
 PM_DEV void ref_window(float4* lw, const float* ctr, int tpitch, int step, int radius, float two_ss, float two_sc, RefWin& rw) {
     const float rc = ctr[0];
     float sw = 0.0f, swr = 0.0f, swrr = 0.0f;
@@ -348,10 +348,7 @@ PM_DEV void ref_window(float4* lw, const float* ctr, int tpitch, int step, int r
             pwrr = __builtin_fmaf(wr, r, pwrr);
         }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            constexpr float k = SCALE24 ? 16777216.0f : 1.0f;
-            lw[(a * 3 + j) * kBlockThreads] = make_float4(wv[2 * j] * k, wv[2 * j + 1] * k, wrv[2 * j] * k, wrv[2 * j + 1] * k);
-        }
+        for (int j = 0; j < 3; ++j) lw[(a * 3 + j) * kBlockThreads] = make_float4(wv[2 * j], wv[2 * j + 1], wrv[2 * j], wrv[2 * j + 1]);
         sw += pw;
         swr += pwr;
         swrr += pwrr;
@@ -384,8 +381,8 @@ PM_DEV int floor_to_int(float c) {
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(c));
     return r;
 }
-// byte k of a packed dword as fp32 (kept as explicit instructions: left to itself
-// hipcc subtracts the bytes as integers first, through slower SDWA forms)
+// byte k of a packed dword as fp32 (kept as explicit instructions: left to itself hipcc subtracts the bytes as integers
+// first, through slower SDWA forms); used by the sky kernel
 template <int K>
 PM_DEV float ubyte_to_float(uint32_t q) {
     float f;
@@ -396,21 +393,45 @@ PM_DEV float ubyte_to_float(uint32_t q) {
     return f;
 }
 
-// byte offset of texel (ix, iy) >= 0, 4 bytes per texel; rows and pitch are
-// below 2^24, so the full-rate 24-bit multiply replaces v_mul_lo_u32
-PM_DEV int texel_offset(int iy, int ix, int pitch) {
-    return (int)((__umul24((unsigned)iy, (unsigned)pitch) + (unsigned)ix) << 2);
+// Texture handle of the cooperative kernels (pm_coop.hpp): ONE wave-uniform buffer resource spans the textures of all
+// source views (they live in one allocation); the view a lane samples is a per-lane byte offset `base` into it, and
+// pitch / clamp limits are per-lane values too.
+struct LaneTex {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int pitch;  // texels per row (= w)
+    float wm1, hm1;
+    int base;   // byte offset of the view's texture
+};
+
+// byte offset of texel (ix, iy), 2^SHIFT bytes per texel
+// PM_DBG_ADDRMASK (measurement builds only, results are wrong): all gathers of a wave fall into a few cache lines, which
+// takes the texture path (TA / L1 / TD) out of the picture while the instruction stream stays the same
+template <int SHIFT, class TEX>
+PM_DEV int tex_byte_offset(const TEX& t, int iy, int ix) {
+    const unsigned idx = __umul24((unsigned)iy, (unsigned)t.pitch) + (unsigned)ix;
+    unsigned off;
+    if constexpr (__is_same(TEX, LaneTex))
+        off = (idx << SHIFT) + (unsigned)t.base;  // v_lshl_add_u32
+    else
+        off = idx << SHIFT;
+#ifdef PM_DBG_ADDRMASK
+    off &= (unsigned)(PM_DBG_ADDRMASK);
+#endif
+    return (int)off;
 }
 
-// Per-view source image handle, fp32 format: w x h float4 texels, texel (x, y) packing
-// its whole bilinear footprint (P[y][x], P[y][x+1], P[y+1][x], P[y+1][x+1]) (indices
-// clamped), so ONE buffer_load_dwordx4 serves a tap.  The 128-bit buffer resource is
-// wave-uniform (built from scalar loads); the 32-bit byte offset is range checked by the
-// hardware (an out-of-range offset -- impossible, the coordinate is clamped first --
-// would read 0 instead of faulting).  Measured on cfg 1 with non-integer images:
-// 4.70 ms per update launch against 5.41 ms for a plain (w+1) x (h+1) image read with two
-// 8-byte loads per tap (the texture-address path, not the cache footprint, is the limit
-// once the gathers are pipelined; before that the two-load form was faster).
+// Source textures ("quad-difference" texels).  Texel (x, y) of a view packs the whole bilinear footprint of the image P
+// (indices clamped to the image) in the form the interpolation consumes:
+//     (t00, d0, t01, d1) = (P[y][x], P[y][x+1] - P[y][x], P[y+1][x], P[y+1][x+1] - P[y+1][x])
+// so that ONE gather serves a tap and the horizontal interpolations are single fmas, fma(ax, d, t), with no unpacking:
+//   * fp32 format (any image): four floats, 16 bytes, one buffer_load_dwordx4.  d is the fp32 difference the canonical
+//     arithmetic defines, rounded once when the texture is packed instead of once per tap.
+//   * fp16 format (every pixel of every source image an integer in [0, 255]: always true for the reference's input unless
+//     it rescales, imread(GRAYSCALE) -> convertTo(CV_32F), ref .cpp:877-882): four halfs, 8 bytes, one
+//     buffer_load_dwordx2; dword 0 = (t00, t01), dword 1 = (d0, d1).  Integers up to 255 and their differences are exact
+//     in fp16, v_fma_mix_f32 reads the half operands directly and rounds once in fp32: identical bits to the fp32 format.
+// The 128-bit buffer resource is wave-uniform (built from scalar loads); the 32-bit byte offset is range checked by the
+// hardware (an out-of-range offset -- impossible, the coordinate is clamped first -- would read 0 instead of faulting).
 struct SrcTex {
     __amdgpu_buffer_rsrc_t rsrc;
     int pitch;  // texels per row (= w)
@@ -427,20 +448,9 @@ PM_DEV SrcTex make_src_tex(const ViewDev& vw) {
     return t;
 }
 
-// Software bilinear fetch with clamp addressing (CUDA tex2D(t, x+0.5, y+0.5), linear
-// filter; ref .cu:377, SURVEY a-2): see BilinearTap below.
-
-// Quad-packed 8-bit texture, used when every pixel of every source image is an
-// integer in [0, 255] (always true for the reference's input unless it rescales:
-// imread(GRAYSCALE) -> convertTo(CV_32F), ref .cpp:877-882).  Entry (x, y) of the
-// (w+1) x (h+1) array packs the whole bilinear footprint of the padded image P,
-//   byte0 = P[y][x], byte1 = P[y][x+1], byte2 = P[y+1][x], byte3 = P[y+1][x+1],
-// so ONE aligned buffer_load_dword per tap replaces two 8-byte loads at the same
-// cache footprint (4 bytes per texel).  u8 -> fp32 conversion is exact, so both
-// formats give bit-identical results.
 struct SrcTex8 {
     __amdgpu_buffer_rsrc_t rsrc;
-    int pitch;  // dwords per row
+    int pitch;  // texels per row (= w)
     float wm1, hm1;
 };
 
@@ -449,83 +459,63 @@ PM_DEV SrcTex8 make_src_tex8(const ViewDev& vw) {
     t.pitch = vw.pitch8;
     t.wm1 = vw.wm1;
     t.hm1 = vw.hm1;
-    const int bytes = vw.pitch8 * vw.h * 4;
+    const int bytes = vw.pitch8 * vw.h * 8;
     t.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(vw.img8), (short)0, bytes, 0x00020000);
     return t;
 }
 
-// Bilinear tap in two halves: issue() clamps the coordinate, computes the address
-// and starts the load(s); value() interpolates.  Lets a whole window column be
-// in flight at once.
+// Bilinear tap in two halves: issue() clamps the coordinate, computes the address and starts the load; value()
+// interpolates (ref .cu:377: tex2D(t, x+0.5, y+0.5) with the linear filter, software here: SURVEY a-2).  Lets a whole
+// window column be in flight at once.
 template <bool U8>
 struct BilinearTap;
-#ifndef PM_U8_HALF_TRICK
-#define PM_U8_HALF_TRICK 1
-#endif
-// are the taps of this texture format scaled by 2^-24 (and the weight records by 2^24)?
-template <bool U8>
-constexpr bool kTapScale24 = U8 && (PM_U8_HALF_TRICK != 0);
 
 typedef float f32x4q __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2q __attribute__((ext_vector_type(2)));
 template <>
 struct BilinearTap<false> {
     float ax, ay;
-    f32x4q q;  // (P[y][x], P[y][x+1], P[y+1][x], P[y+1][x+1])
-    PM_DEV void issue(const SrcTex& t, float sx, float sy) {
+    f32x4q q;  // (t00, d0, t01, d1)
+    template <class TEX>
+    PM_DEV void issue(const TEX& t, float sx, float sy) {
         const float cx = clamp_coord(sx, t.wm1);
         const float cy = clamp_coord(sy, t.hm1);
-        ax = __builtin_amdgcn_fractf(cx);
+        ax = __builtin_amdgcn_fractf(cx);  // v_fract_f32: x - floor(x), kept below 1
         ay = __builtin_amdgcn_fractf(cy);
-        const int off = texel_offset(floor_to_int(cy), floor_to_int(cx), t.pitch) << 2;
+        const int off = tex_byte_offset<4>(t, floor_to_int(cy), floor_to_int(cx));
         q = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(t.rsrc, off, 0, 0));
     }
     PM_DEV float value() const {
-        const float top = __builtin_fmaf(ax, q.y - q.x, q.x);
-        const float bot = __builtin_fmaf(ax, q.w - q.z, q.z);
+        const float top = __builtin_fmaf(ax, q.y, q.x);
+        const float bot = __builtin_fmaf(ax, q.w, q.z);
         return __builtin_fmaf(ay, bot - top, top);
     }
 };
 template <>
 struct BilinearTap<true> {
     float ax, ay;
-    uint32_t q;
-    PM_DEV void issue(const SrcTex8& t, float sx, float sy) {
+    u32x2q q;  // halfs: (t00, t01), (d0, d1)
+    template <class TEX>
+    PM_DEV void issue(const TEX& t, float sx, float sy) {
         const float cx = clamp_coord(sx, t.wm1);
         const float cy = clamp_coord(sy, t.hm1);
-        ax = __builtin_amdgcn_fractf(cx);  // v_fract_f32: x - floor(x), kept below 1
+        ax = __builtin_amdgcn_fractf(cx);
         ay = __builtin_amdgcn_fractf(cy);
-        const int off = texel_offset(floor_to_int(cy), floor_to_int(cx), t.pitch);
-        q = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(t.rsrc, off, 0, 0);
-    }
-#if PM_U8_HALF_TRICK
-    // A byte n in a 16-bit lane IS the fp16 subnormal n * 2^-24.  So the four texels never pass through v_cvt_f32_ubyte:
-    // two bit operations spread them into the half2 registers (t00, t01) and (t10, t11), one packed fp16 subtraction gives
-    // both horizontal differences (exact: integers below 2^11 in units of 2^-24), and the two horizontal interpolations
-    // read their fp16 operands directly (v_fma_mix_f32).  Every value is 2^-24 times the one the fp32 formulation computes,
-    // rounding included (a power-of-two scaling commutes with rounding as long as nothing underflows), and the weight
-    // records are stored times 2^24, so w * s, (w r) * s are the identical floats and sum(w s^2) comes out times 2^-24,
-    // undone once per evaluation.  7 issue slots per tap instead of 10.
-    PM_DEV float value() const {
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        const h2 A = __builtin_bit_cast(h2, q & 0x00FF00FFu);                              // (t00, t01)
-        const h2 B = __builtin_bit_cast(h2, __builtin_amdgcn_perm(0u, q, 0x0C030C01u));     // (t10, t11)
-        const h2 D = B - A;
-        // fma(ax, (float)D.lo, (float)A.lo) and the same on the high halves, without separate conversions (hipcc does not
-        // form v_fma_mix_f32 from the fpext + fma pattern here)
-        float top, bot;
-        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(top) : "v"(ax), "v"(D), "v"(A));
-        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[0,1,1]" : "=v"(bot) : "v"(ax), "v"(D), "v"(A));
-        return __builtin_fmaf(ay, bot - top, top);
-    }
+        const int off = tex_byte_offset<3>(t, floor_to_int(cy), floor_to_int(cx));
+#ifdef PM_DBG_NOLOAD  // measurement builds only (results are wrong): the instruction stream without its gathers
+        q = (u32x2q){(uint32_t)off, (uint32_t)off};
 #else
+        q = __builtin_bit_cast(u32x2q, __builtin_amdgcn_raw_buffer_load_b64(t.rsrc, off, 0, 0));
+#endif
+    }
     PM_DEV float value() const {
-        const float t00 = ubyte_to_float<0>(q), t10 = ubyte_to_float<1>(q);
-        const float t01 = ubyte_to_float<2>(q), t11 = ubyte_to_float<3>(q);
-        const float top = __builtin_fmaf(ax, t10 - t00, t00);
-        const float bot = __builtin_fmaf(ax, t11 - t01, t01);
+        // fma(ax, (float)d0, (float)t00) and the same on the high halves, the fp16 operands read in place (hipcc does not form
+        // v_fma_mix_f32 from the fpext + fma pattern here)
+        float top, bot;
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(top) : "v"(ax), "v"(q.y), "v"(q.x));
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[0,1,1]" : "=v"(bot) : "v"(ax), "v"(q.y), "v"(q.x));
         return __builtin_fmaf(ay, bot - top, top);
     }
-#endif
 };
 
 // plane -> m = (n^T K_r^-1) / d, shared by all views of one hypothesis
@@ -536,32 +526,20 @@ PM_DEV void plane_to_m(const ProblemDev& P, const float4 pl, float& m0, float& m
     m2 = __builtin_fmaf(-pl.y, P.cyfy, __builtin_fmaf(-pl.x, P.cxfx, pl.z)) * inv_d;
 }
 
-// ref .cu:325-414 ComputeBilateralNCC for one (hypothesis, source view)
-template <bool U8>
-PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int step, int radius, float m0, float m1, float m2) {
-    const float H0 = __builtin_fmaf(-vw.b[0], m0, vw.A[0]);
-    const float H1 = __builtin_fmaf(-vw.b[0], m1, vw.A[1]);
-    const float H2 = __builtin_fmaf(-vw.b[0], m2, vw.A[2]);
-    const float H3 = __builtin_fmaf(-vw.b[1], m0, vw.A[3]);
-    const float H4 = __builtin_fmaf(-vw.b[1], m1, vw.A[4]);
-    const float H5 = __builtin_fmaf(-vw.b[1], m2, vw.A[5]);
-    const float H6 = __builtin_fmaf(-vw.b[2], m0, vw.A[6]);
-    const float H7 = __builtin_fmaf(-vw.b[2], m1, vw.A[7]);
-    const float H8 = __builtin_fmaf(-vw.b[2], m2, vw.A[8]);
+// ref .cu:325-414 ComputeBilateralNCC for one (hypothesis, source view), given the homography H = A - b m^T of the
+// pair, the texture handle of the view (wave-uniform SrcTex / SrcTex8, or per-lane LaneTex) and the LDS weight records of
+// the pixel (rw.lw[rec * LWSTRIDE]).
+template <bool U8, int LWSTRIDE, class TEX>
+PM_DEV float ncc_core(const TEX& tex, float wf, float hf, float H0, float H1, float H2, float H3, float H4, float H5, float H6, float H7, float H8,
+                      const RefWin& rw, int px, int py, int step, int radius) {
     const float fpx = (float)px, fpy = (float)py;
-    const auto tex = [&] {
-        if constexpr (U8)
-            return make_src_tex8(vw);
-        else
-            return make_src_tex(vw);
-    }();
     {
         const float X = __builtin_fmaf(H1, fpy, __builtin_fmaf(H0, fpx, H2));
         const float Y = __builtin_fmaf(H4, fpy, __builtin_fmaf(H3, fpx, H5));
         const float Z = __builtin_fmaf(H7, fpy, __builtin_fmaf(H6, fpx, H8));
         const float rz = d_rcp(Z);
         const float cx = X * rz, cy = Y * rz;
-        if (!(cx >= 0.0f && cx < vw.wf && cy >= 0.0f && cy < vw.hf)) return 2.0f;  // ref .cu:351-353
+        if (!(cx >= 0.0f && cx < wf && cy >= 0.0f && cy < hf)) return 2.0f;  // ref .cu:351-353
     }
     float T1 = 0.0f, T2 = 0.0f, T3 = 0.0f;
     const f32x2 h1 = {H1, H1}, h4 = {H4, H4}, h7 = {H7, H7};
@@ -665,7 +643,7 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int s
     // weight records of a column are fetched one column ahead for the same reason
     auto load_weights = [&](int a, float4(&wq)[3]) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) wq[j] = rw.lw[(a * 3 + j) * kBlockThreads];
+        for (int j = 0; j < 3; ++j) wq[j] = rw.lw[(a * 3 + j) * LWSTRIDE];
     };
     BilinearTap<U8> tapA[6], tapB[6];
     float4 wA[3], wB[3];
@@ -682,7 +660,6 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int s
         }
         consume_column(wB, tapB);
     }
-    if (kTapScale24<U8>) T2 *= 16777216.0f;  // sum(w s^2) was accumulated times 2^-24 (exact)
     const float ms = T1 * rw.inv_w, mss = T2 * rw.inv_w, mrs = T3 * rw.inv_w;
     const float var_s = __builtin_fmaf(-ms, ms, mss);
     if (rw.var_r < 1e-5f || var_s < 1e-5f) return 2.0f;  // ref .cu:406-408
@@ -692,6 +669,27 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int s
     cost = (cost < 2.0f) ? cost : 2.0f;  // ref .cu:412
     cost = (cost > 0.0f) ? cost : 0.0f;
     return cost;
+}
+
+// one-thread-per-pixel kernels: wave-uniform source view (constants through the scalar cache)
+template <bool U8>
+PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int step, int radius, float m0, float m1, float m2) {
+    const float H0 = __builtin_fmaf(-vw.b[0], m0, vw.A[0]);
+    const float H1 = __builtin_fmaf(-vw.b[0], m1, vw.A[1]);
+    const float H2 = __builtin_fmaf(-vw.b[0], m2, vw.A[2]);
+    const float H3 = __builtin_fmaf(-vw.b[1], m0, vw.A[3]);
+    const float H4 = __builtin_fmaf(-vw.b[1], m1, vw.A[4]);
+    const float H5 = __builtin_fmaf(-vw.b[1], m2, vw.A[5]);
+    const float H6 = __builtin_fmaf(-vw.b[2], m0, vw.A[6]);
+    const float H7 = __builtin_fmaf(-vw.b[2], m1, vw.A[7]);
+    const float H8 = __builtin_fmaf(-vw.b[2], m2, vw.A[8]);
+    const auto tex = [&] {
+        if constexpr (U8)
+            return make_src_tex8(vw);
+        else
+            return make_src_tex(vw);
+    }();
+    return ncc_core<U8, kBlockThreads>(tex, vw.wf, vw.hf, H0, H1, H2, H3, H4, H5, H6, H7, H8, rw, px, py, step, radius);
 }
 
 // ---------------------------------------------------------------------------

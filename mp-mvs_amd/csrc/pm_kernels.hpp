@@ -48,14 +48,13 @@ __device__ constexpr Off kDirs[8][12] = {
     {{5, 0}, {7, 0}, {9, 0}, {11, 0}, {13, 0}, {15, 0}, {17, 0}, {19, 0}, {21, 0}, {23, 0}, {0, 0}, {0, 0}}};
 __device__ constexpr int kNumDirs[8] = {12, 12, 12, 12, 10, 10, 10, 10};
 
-// Wave shape of the checkerboard launches: PM_WAVE_ROWS rows of 64/PM_WAVE_ROWS
-// same-colour pixels; a 256-thread block stacks its 4 waves vertically.
-// Measured (update launch, cfg 1).  Early kernel (gathers serialised): 8 rows (16x8 px patch) 8.13 ms, 4 rows 8.45,
-// 2 rows 8.59, 1 row 8.87 -- compact 2-D patches reuse more L1 lines between taps.  Final kernel (LDS weights, pipelined
-// gathers): 4 rows (32x4 px) 3.853, 8 rows 3.891, 2 rows 3.981, 16 rows 4.835; geometric mode 4.81 vs 5.13.
-// The fp32 texture format (16-byte gathers) prefers the taller patch: 4.70 ms with 8 rows against 4.95 with 4.
+// Wave shape of the checkerboard launches: PM_WAVE_ROWS rows of 64/PM_WAVE_ROWS same-colour pixels; a 256-thread block
+// stacks its 4 waves vertically.  Compact 2-D patches reuse more L1 lines between taps than flat rows, and the wider the
+// texel the taller the best patch.  Measured per update launch, cfg 1 (round 2, quad-difference textures): fp16 texels
+// (8 bytes) 2 / 4 / 8 / 16 rows: 4.00 / 3.66 / 3.50 / 3.45 ms; fp32 texels (16 bytes) 4 / 8 / 16 / 32 rows: 4.72 / 4.47 /
+// 4.57 / 5.90 ms.  (Round 1, 4-byte u8 quads: 4 rows 3.85, 8 rows 3.89, 2 rows 3.98, 16 rows 4.84.)
 #ifndef PM_WAVE_ROWS
-#define PM_WAVE_ROWS 4
+#define PM_WAVE_ROWS 16
 #endif
 #ifndef PM_WAVE_ROWS_F32
 #define PM_WAVE_ROWS_F32 8
@@ -148,7 +147,7 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_init(const ProblemDe
     const int V = P.V;
     Rng g = rng_make(a.seed, (uint32_t)idx, a.launch);
     RefWin rw;
-    ref_window<kTapScale24<U8>>((float4*)pm_lds + threadIdx.x, ctr, tpitch, step, radius, a.two_ss, a.two_sc, rw);
+    ref_window((float4*)pm_lds + threadIdx.x, ctr, tpitch, step, radius, a.two_ss, a.two_sc, rw);
 
     float4 pl;
     if (a.init_random) {
@@ -226,7 +225,7 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
     const int idx = y * W + x;
     Rng g = rng_make(a.seed, (uint32_t)idx, a.launch);
     RefWin rw;
-    ref_window<kTapScale24<U8>>((float4*)pm_lds + threadIdx.x, ctr, tpitch, step, radius, a.two_ss, a.two_sc, rw);
+    ref_window((float4*)pm_lds + threadIdx.x, ctr, tpitch, step, radius, a.two_ss, a.two_sc, rw);
 
     // -- 8 sampling regions: position of the lowest stored cost (ref .cu:798-816)
     int pos[8];
@@ -584,23 +583,27 @@ __global__ void k_pad(const float* __restrict__ src, int w, int h, float* __rest
     dst[(long)y * pw + x] = src[(long)sy * w + sx];
 }
 
-// dense 8-bit w x h image -> quad-packed u8 texture (SrcTex8), w x h dwords; the host converts the fp32 input to 8 bit
-// while it checks that every pixel is an integer in [0, 255] (4x less PCIe traffic than staging fp32)
-__global__ void k_pack_quads_u8(const unsigned char* __restrict__ src, int w, int h, uint32_t* __restrict__ dst) {
+// dense 8-bit w x h image -> fp16 quad-difference texture (SrcTex8), w x h texels of 8 bytes; the host converts the fp32 input
+// to 8 bit while it checks that every pixel is an integer in [0, 255] (4x less PCIe traffic than staging fp32)
+__global__ void k_pack_quads_u8(const unsigned char* __restrict__ src, int w, int h, uint2* __restrict__ dst) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w || y >= h) return;
     const int x1 = x + 1 > w - 1 ? w - 1 : x + 1, y1 = y + 1 > h - 1 ? h - 1 : y + 1;
-    const uint32_t b0 = src[(long)y * w + x], b1 = src[(long)y * w + x1];
-    const uint32_t b2 = src[(long)y1 * w + x], b3 = src[(long)y1 * w + x1];
-    dst[(long)y * w + x] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    const int t00 = src[(long)y * w + x], t10 = src[(long)y * w + x1];
+    const int t01 = src[(long)y1 * w + x], t11 = src[(long)y1 * w + x1];
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 lo = {(_Float16)(float)t00, (_Float16)(float)t01};                  // exact: integers up to 255
+    const h2 hi = {(_Float16)(float)(t10 - t00), (_Float16)(float)(t11 - t01)};  // exact: |difference| <= 255
+    dst[(long)y * w + x] = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
 }
 
-// dense w x h image -> w x h float4 texels packing the 2x2 bilinear footprint (SrcTex)
+// dense w x h image -> fp32 quad-difference texture (SrcTex), w x h float4 texels
 __global__ void k_pack_quads_f32(const float* __restrict__ src, int w, int h, float4* __restrict__ dst) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w || y >= h) return;
     const int x1 = x + 1 > w - 1 ? w - 1 : x + 1, y1 = y + 1 > h - 1 ? h - 1 : y + 1;
-    dst[(long)y * w + x] = make_float4(src[(long)y * w + x], src[(long)y * w + x1], src[(long)y1 * w + x], src[(long)y1 * w + x1]);
+    const float t00 = src[(long)y * w + x], t10 = src[(long)y * w + x1], t01 = src[(long)y1 * w + x], t11 = src[(long)y1 * w + x1];
+    dst[(long)y * w + x] = make_float4(t00, t10 - t00, t01, t11 - t01);
 }
 
 __global__ void k_export_depth(const float4* __restrict__ planes, float* __restrict__ out, int n) {
@@ -608,8 +611,9 @@ __global__ void k_export_depth(const float4* __restrict__ planes, float* __restr
     if (i < n) out[i] = planes[i].w;
 }
 
+// probe: nh planes per pixel ([nh][H][W]) against every view; out [nh][V][H][W]
 template <int MAXV, bool U8>
-__global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_eval_ncc(const ProblemDev* __restrict__ Pp, const float4* __restrict__ planes, float* __restrict__ out, LaunchArgs a) {
+__global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_eval_ncc(const ProblemDev* __restrict__ Pp, const float4* __restrict__ planes, int nh, float* __restrict__ out, LaunchArgs a) {
     const ProblemDev& P = *Pp;
     int x, y, x0, y0;
     const bool valid = dense_pixel(P, x, y, x0, y0);
@@ -619,11 +623,13 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_eval_ncc(const Probl
     if (!valid) return;
     const int idx = y * P.W + x;
     RefWin rw;
-    ref_window<kTapScale24<U8>>((float4*)pm_lds + threadIdx.x, ctr, tpitch, step, radius, a.two_ss, a.two_sc, rw);
-    float m0, m1, m2;
-    plane_to_m(P, planes[idx], m0, m1, m2);
+    ref_window((float4*)pm_lds + threadIdx.x, ctr, tpitch, step, radius, a.two_ss, a.two_sc, rw);
     const long wh = (long)P.W * P.H;
-    for (int v = 0; v < P.V; ++v) out[v * wh + idx] = ncc_cost<U8>(P.views[v], rw, x, y, step, radius, m0, m1, m2);
+    for (int h = 0; h < nh; ++h) {
+        float m0, m1, m2;
+        plane_to_m(P, planes[h * wh + idx], m0, m1, m2);
+        for (int v = 0; v < P.V; ++v) out[((long)h * P.V + v) * wh + idx] = ncc_cost<U8>(P.views[v], rw, x, y, step, radius, m0, m1, m2);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_eval_geom(const ProblemDev* __restrict__ Pp, const float4* __restrict__ planes, float* __restrict__ out) {

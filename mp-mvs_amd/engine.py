@@ -21,6 +21,7 @@ _EXTRA = {
     "set_texture_format": (C.c_int, [_P, C.c_int]),
     "texture_format": (C.c_int, [_P]),
     "get_kernel_times": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "eval_ncc_multi": (C.c_int, [_P, C.POINTER(_abi.PatchMatchParams), _P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_float)]),
 }
 ALL_SYMBOLS = ["mpmvs_" + n for n in list(_abi.SIGNATURES) + list(_EXTRA)] + ["mpmvs_fuse", "mpmvs_fuse_kernel_ms", "mpmvs_sky_bilateral", "mpmvs_sky_kernel_ms", "mpmvs_fuse_ply", "mpmvs_free"]
 
@@ -80,6 +81,18 @@ class HipPatchMatch(_abi.PatchMatchHandle):
         cnt = (C.c_int * 6)()
         self._chk(self._f["get_kernel_times"](self._ctx, ms, cnt), "get_kernel_times")
         return list(ms), list(cnt)
+
+    def eval_ncc_multi(self, params, planes_cam, scale, mapping=0):
+        """ComputeBilateralNCC of nh planes per pixel ([nh][H][W][4]) against every view -> ([nh][V][H][W], kernel ms);
+        mapping 0 = one thread per pixel, 1..4 = cooperative lane groups (include/mpmvs.h)"""
+        import numpy as np
+        p = np.ascontiguousarray(planes_cam, np.float32)
+        nh = p.shape[0]
+        assert p.shape == (nh, self.H, self.W, 4)
+        out = np.empty((nh, params.num_images - 1, self.H, self.W), np.float32)
+        ms = C.c_float(0.0)
+        self._chk(self._f["eval_ncc_multi"](self._ctx, C.byref(params), p.ctypes.data, nh, int(scale), int(mapping), out.ctypes.data, C.byref(ms)), "eval_ncc_multi")
+        return out, float(ms.value)
 
     def set_src_depths_device(self, ptrs, widths, heights):
         n = len(ptrs)

@@ -1,0 +1,94 @@
+"""north_star's tolerance tested ON THE GPU against the closest thing to the reference's own formulas that can run here: the
+oracle's LITERAL transcription of ComputeBilateralNCC (reference src/PatchMatch.cu:228-414: homography assembled per
+evaluation with its divisions, one perspective division per tap, libm expf/sqrtf, row-by-row sums, nothing hoisted), mode 1,
+and the same with CUDA's 8-bit texture interpolation fractions, mode 2 (`orc_set_literal_mode`).  The canonical arithmetic the
+HIP kernels implement is bit-exact against the oracle's canonical mode (tests/test_parity_gpu.py); these
+tests bound its distance to the literal formulas.
+
+T1  NCC costs (range [0, 2]) on a 400x300 cfg-1 scene, 8 views, window scales 0..2, planes from the true surface to fully
+    random.  Against the literal formulas (mode 1) the bar is north_star's 1e-3: at most 1e-5 of the evaluations may exceed it
+    (measured: 1 of 960 000 at 1.1e-3, a window whose source variance is just above the 1e-5 threshold), none 2e-3.  CUDA's
+    8-bit fractions (mode 2) are a property of the sampler hardware, not of the formulas: they alone move costs by up to
+    2e-3, so that bar is 99.9 % within 1e-3 and none beyond 3e-3.
+T3  the whole Run() schedule: individual decisions differ (ties flip, then the random walks diverge), the statistics must
+    not: pixels within 1 % of the analytic ground-truth depth +-0.5 pp, mean matching cost +-2 %.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W, H, V = 400, 300, 8
+
+
+@pytest.fixture(scope="module")
+def scene(pm, oracle, engine):
+    sc = pm.synth.make_problem_scene(W, H, n_src=V, quantize=True)
+    cams, imgs = sc.problem(0, list(range(1, V + 1)))
+    dmin, dmax = pm.synth.kernel_depth_range(cams[0])
+    gpu = engine.create(0)
+    gpu.set_views(cams, imgs)
+    cpu = oracle.create()
+    cpu.set_views(cams, imgs)
+    return sc, cams, imgs, gpu, cpu, float(dmin), float(dmax)
+
+
+def test_T1_ncc_costs_vs_literal_formulas(pm, oracle, scene):
+    sc, cams, imgs, gpu, cpu, dmin, dmax = scene
+    prm = pm.PatchMatchParams(num_images=V + 1, depth_min=dmin, depth_max=dmax, max_scale=0)
+    cam = sc.views[0].cam
+    rng = np.random.default_rng(11)
+    gt = sc.views[0].gt_depth.astype(np.float64)
+    u, v = np.meshgrid(np.arange(W), np.arange(H))
+    worst = {1: 0.0, 2: 0.0}
+    for depth, tilt in [(gt, 0.0), (gt * rng.uniform(0.9, 1.1, gt.shape), 0.3), (rng.uniform(dmin, dmax, gt.shape), 1.0)]:
+        n = np.zeros((H, W, 3))
+        n[..., 2] = -1.0
+        n[..., :2] = tilt * rng.normal(size=(H, W, 2))
+        n /= np.linalg.norm(n, axis=-1, keepdims=True)
+        X = np.stack([depth * (u - cam.K[2]) / cam.K[0], depth * (v - cam.K[5]) / cam.K[4], depth], -1)
+        planes = np.concatenate([n, -(n * X).sum(-1)[..., None]], -1).astype(np.float32)
+        for scale in (0, 1, 2):
+            hip = gpu.eval_ncc(prm, planes, scale)
+            for mode in (1, 2):
+                lit = oracle.eval_ncc_literal(cpu, prm, planes, scale, quantize_fraction=(mode == 2))
+                both = (hip < 2.0) & (lit < 2.0)
+                assert both.mean() > 0.5
+                assert ((hip == 2.0) != (lit == 2.0)).mean() < 1e-3     # window centre on the image border / variance threshold
+                d = np.abs(hip - lit)[both]
+                worst[mode] = max(worst[mode], float(d.max()))
+                if mode == 1:
+                    assert (d > 1e-3).mean() <= 1e-5, (scale, tilt, float(d.max()))
+                    assert d.max() < 2e-3
+                    assert np.median(d) < 5e-5
+                else:
+                    assert (d > 1e-3).mean() <= 1e-3, (scale, tilt, float(d.max()))
+                    assert d.max() < 3e-3
+    print(f"max |HIP - literal| = {worst[1]:.2e}, max |HIP - literal with 8-bit fractions| = {worst[2]:.2e}")
+
+
+def test_T3_schedule_statistics_vs_literal_formulas(pm, oracle, scene):
+    sc, cams, imgs, gpu, cpu, dmin, dmax = scene
+    gt = sc.views[0].gt_depth
+    prm = pm.PatchMatchParams(num_images=V + 1, depth_min=dmin, depth_max=dmax, max_scale=2)
+    stats = {}
+    for mode in (0, 1, 2):
+        acc, cost = [], []
+        for seed in (1, 2):
+            if mode == 0:
+                gpu.run(prm, seed)
+                planes, costs = gpu.get()
+            else:
+                oracle.set_literal_mode(cpu, mode)
+                cpu.run(prm, seed)
+                planes, costs = cpu.get()
+                oracle.set_literal_mode(cpu, 0)
+            rel = np.abs(planes[..., 3] - gt) / gt
+            acc.append(float((rel < 0.01).mean()))
+            cost.append(float(costs.mean()))
+        stats[mode] = (np.mean(acc), np.mean(cost))
+    print("within 1 %% of GT / mean cost: HIP %.4f %.5f, literal %.4f %.5f, literal + 8-bit %.4f %.5f" % (stats[0] + stats[1] + stats[2]))
+    assert stats[0][0] > 0.9                                              # the schedule converges on this scene
+    for mode in (1, 2):
+        assert abs(stats[mode][0] - stats[0][0]) < 0.005, stats
+        assert abs(stats[mode][1] / stats[0][1] - 1.0) < 0.02, stats

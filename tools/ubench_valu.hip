@@ -84,6 +84,37 @@ extern __shared__ float lds_pin[];
 #define I_SQRT(d) "v_sqrt_f32 " d ", " d "\n"
 #define I_CVTUB(d) "v_cvt_f32_ubyte1 " d ", " d "\n"
 #define I_MOV(d) "v_mov_b32 " d ", %8\n"
+#define I_FLOOR(d) "v_floor_f32 " d ", " d "\n"
+#define I_TRUNC(d) "v_trunc_f32 " d ", " d "\n"
+#define I_RNDNE(d) "v_rndne_f32 " d ", " d "\n"
+#define I_CVTI32(d) "v_cvt_i32_f32 " d ", " d "\n"
+#define I_CVTU32(d) "v_cvt_u32_f32 " d ", " d "\n"
+#define I_CVTF32I(d) "v_cvt_f32_i32 " d ", " d "\n"
+#define I_CVTF32U(d) "v_cvt_f32_u32 " d ", " d "\n"
+#define I_MAX(d) "v_max_f32 " d ", " d ", %8\n"
+#define I_MIN(d) "v_min_f32 " d ", " d ", %8\n"
+#define I_SUB(d) "v_sub_f32 " d ", " d ", %8\n"
+#define I_LSHL(d) "v_lshlrev_b32 " d ", 2, " d "\n"
+#define I_ADDU(d) "v_add_u32 " d ", " d ", %8\n"
+#define I_SUBU(d) "v_sub_u32 " d ", " d ", %8\n"
+#define I_MULU24(d) "v_mul_u32_u24 " d ", " d ", %8\n"
+#define I_MULLO(d) "v_mul_lo_u32 " d ", " d ", %8\n"
+#define I_OR(d) "v_or_b32 " d ", " d ", %8\n"
+#define I_BFE(d) "v_bfe_u32 " d ", " d ", 8, 8\n"
+#define I_CNDMASK(d) "v_cndmask_b32 " d ", " d ", %8, vcc\n"
+#define I_FMAC(d) "v_fmac_f32 " d ", %8, %9\n"
+#define I_MAX3(d) "v_max3_f32 " d ", " d ", %8, %9\n"
+#define I_ADD3(d) "v_add3_u32 " d ", " d ", %8, %9\n"
+#define I_LSHLOR(d) "v_lshl_or_b32 " d ", " d ", 2, %8\n"
+#define I_MOVDPP(d) "v_mov_b32_dpp " d ", " d " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define I_ADDDPP(d) "v_add_f32_dpp " d ", " d ", %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define I_CVTPKRTZ(d) "v_cvt_pkrtz_f16_f32 " d ", " d ", %8\n"
+#define I_MADMIX(d) "v_fma_mixlo_f16 " d ", " d ", %8, %9\n"
+#define I_PKMULH(d) "v_pk_mul_f16 " d ", " d ", %8\n"
+#define I_PKFMAH(d) "v_pk_fma_f16 " d ", " d ", %8, %9\n"
+#define I_EXP(d) "v_exp_f32 " d ", " d "\n"
+#define I_MULLEG(d) "v_mul_legacy_f32 " d ", " d ", %8\n"
+#define I_CVTFLRPAIR(d) "v_cvt_flr_i32_f32 " d ", " d "\nv_fma_f32 " d ", " d ", %8, %9\n"
 #define I_PKFMA(d) "v_pk_fma_f32 " d ", " d ", %8, %9\n"
 #define I_PKMUL(d) "v_pk_mul_f32 " d ", " d ", %8\n"
 #define I_PKADD(d) "v_pk_add_f32 " d ", " d ", %8\n"
@@ -104,6 +135,37 @@ KERNEL(k_rcp, I_RCP)
 KERNEL(k_sqrt, I_SQRT)
 KERNEL(k_cvtub, I_CVTUB)
 KERNEL(k_mov, I_MOV)
+KERNEL(k_floor, I_FLOOR)
+KERNEL(k_trunc, I_TRUNC)
+KERNEL(k_rndne, I_RNDNE)
+KERNEL(k_cvti32, I_CVTI32)
+KERNEL(k_cvtu32, I_CVTU32)
+KERNEL(k_cvtf32i, I_CVTF32I)
+KERNEL(k_cvtf32u, I_CVTF32U)
+KERNEL(k_max, I_MAX)
+KERNEL(k_min, I_MIN)
+KERNEL(k_sub, I_SUB)
+KERNEL(k_lshl, I_LSHL)
+KERNEL(k_addu, I_ADDU)
+KERNEL(k_subu, I_SUBU)
+KERNEL(k_mulu24, I_MULU24)
+KERNEL(k_mullo, I_MULLO)
+KERNEL(k_or, I_OR)
+KERNEL(k_bfe, I_BFE)
+KERNEL(k_cndmask, I_CNDMASK)
+KERNEL(k_fmac, I_FMAC)
+KERNEL(k_max3, I_MAX3)
+KERNEL(k_add3, I_ADD3)
+KERNEL(k_lshlor, I_LSHLOR)
+KERNEL(k_movdpp, I_MOVDPP)
+KERNEL(k_adddpp, I_ADDDPP)
+KERNEL(k_cvtpkrtz, I_CVTPKRTZ)
+KERNEL(k_madmix, I_MADMIX)
+KERNEL(k_pkmulh, I_PKMULH)
+KERNEL(k_pkfmah, I_PKFMAH)
+KERNEL(k_exp, I_EXP)
+KERNEL(k_mulleg, I_MULLEG)
+KERNEL(k_flrfma, I_CVTFLRPAIR)
 KERNEL2(k_pkfma, I_PKFMA)
 KERNEL2(k_pkmul, I_PKMUL)
 KERNEL2(k_pkadd, I_PKADD)
@@ -120,7 +182,15 @@ int main() {
                          {"v_mad_u32_u24", k_mad24},   {"v_lshl_add_u32", k_lshladd}, {"v_perm_b32", k_perm},
                          {"v_and_b32", k_and},         {"v_fma_mix_f32", k_fmamix},  {"v_pk_add_f16", k_pkaddh},
                          {"v_rcp_f32", k_rcp},         {"v_sqrt_f32", k_sqrt},       {"v_cvt_f32_ubyte1", k_cvtub},
-                         {"v_mov_b32", k_mov},         {"v_pk_fma_f32", k_pkfma},    {"v_pk_mul_f32", k_pkmul},
+                         {"v_mov_b32", k_mov},
+                         {"v_floor_f32", k_floor}, {"v_trunc_f32", k_trunc}, {"v_rndne_f32", k_rndne}, {"v_cvt_i32_f32", k_cvti32}, {"v_cvt_u32_f32", k_cvtu32},
+                         {"v_cvt_f32_i32", k_cvtf32i}, {"v_cvt_f32_u32", k_cvtf32u}, {"v_max_f32", k_max}, {"v_min_f32", k_min}, {"v_sub_f32", k_sub},
+                         {"v_lshlrev_b32", k_lshl}, {"v_add_u32", k_addu}, {"v_sub_u32", k_subu}, {"v_mul_u32_u24", k_mulu24}, {"v_mul_lo_u32", k_mullo},
+                         {"v_or_b32", k_or}, {"v_bfe_u32", k_bfe}, {"v_cndmask_b32", k_cndmask}, {"v_fmac_f32", k_fmac}, 
+                         {"v_max3_f32", k_max3}, {"v_add3_u32", k_add3}, {"v_lshl_or_b32", k_lshlor}, {"v_mov_b32_dpp quad", k_movdpp},
+                         {"v_add_f32_dpp quad", k_adddpp}, {"v_cvt_pkrtz_f16_f32", k_cvtpkrtz}, {"v_fma_mixlo_f16", k_madmix}, {"v_pk_mul_f16", k_pkmulh},
+                         {"v_pk_fma_f16", k_pkfmah}, {"v_exp_f32", k_exp}, {"v_mul_legacy_f32", k_mulleg}, {"cvt_flr+fma pair (x2)", k_flrfma},
+                         {"v_pk_fma_f32", k_pkfma},    {"v_pk_mul_f32", k_pkmul},
                          {"v_pk_add_f32", k_pkadd}};
     hipDeviceProp_t prop;
     CHK(hipGetDeviceProperties(&prop, 0));
