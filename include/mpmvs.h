@@ -113,9 +113,28 @@ int mpmvs_set_state(mpmvs_ctx* ctx, const void* planes4, const void* costs);
 /* selected-view bitmasks (cudaSelectedViews, include/PatchMatch.h:108); only
  * needed to reproduce a single kernel step from a given state */
 int mpmvs_set_selected_views(mpmvs_ctx* ctx, const void* sel_u32);
+/* geometric costs (cudaGeomCosts, include/PatchMatch.h:110; written by a geometric Run()); only needed to reproduce the
+ * vertex selection of the prior from a given state */
+int mpmvs_set_geom_costs(mpmvs_ctx* ctx, const void* geom_costs);
 /* CudaPlanarPriorInitialization (src/PatchMatch.cpp:978-996): per-pixel prior
  * plane (n, d) in the reference-camera frame and mask (>0 = has prior) */
 int mpmvs_set_prior(mpmvs_ctx* ctx, const void* prior_planes4, const void* mask_u32);
+
+/* ---- planar prior built on the device (the host block of ProcessProblem between its two Run() calls,
+ * src/PatchMatch.cpp:532-604): the maps of the first Run() stay in HBM, only the vertex list and the triangle list cross
+ * PCIe; the Delaunay triangulation itself stays with the caller (mp-mvs_amd/host: PatchMatchCUDA::DelaunayTriangulation). */
+/* GetTriangulateVertices (src/PatchMatch.cpp:782-853) from the costs (geom_rule != 0: and geometric costs, the
+ * geomPlanarPrior branch :810-850) the last mpmvs_run left on the device: per 5x5 cell the reliable pixels, in cell raster
+ * order.  out_xy receives (x, y) pairs of at most cap vertices; *n the number found (if it exceeds cap, call again). */
+int mpmvs_prior_vertices(mpmvs_ctx* ctx, int geom_rule, int* out_xy, int cap, int* n);
+/* triangle rasterisation (src/PatchMatch.cpp:554-570, a later triangle overwrites an earlier one), GetPriorPlaneParams
+ * (:723-755) with the depths of the last mpmvs_run, the depth-range test (:583-595, params->depth_min/max) and
+ * CudaPlanarPriorInitialization (:978-996), all on the device.  tri_xy = n x {x1 y1 x2 y2 x3 y3}, every vertex inside
+ * the image (the caller drops the others as :555 does); triangle k is label k + 1.  Installs the prior like
+ * mpmvs_set_prior. */
+int mpmvs_prior_from_triangles(mpmvs_ctx* ctx, const mpmvs_params* params, const int* tri_xy, int n);
+/* the installed prior planes (float4) and mask (u32) back on the host, for tests; either may be NULL */
+int mpmvs_get_prior(mpmvs_ctx* ctx, void* prior_planes4, void* mask_u32);
 
 /* PatchMatchCUDA::Run() (src/PatchMatch.cu:1188-1254) without its final
  * device-to-host copies: InitializeScore, the red/black schedule selected by

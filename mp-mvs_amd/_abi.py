@@ -244,6 +244,11 @@ class PatchMatchHandle:
         self._chk(self._f["get"](self._ctx, planes.ctypes.data, costs.ctypes.data, g.ctypes.data if geom else None), "get")
         return (planes, costs, g) if geom else (planes, costs)
 
+    def get_into(self, planes, costs, geom=None):
+        """the same into caller-owned (e.g. pinned) float32 arrays of the right shape"""
+        assert planes.shape == (self.H, self.W, 4) and costs.shape == (self.H, self.W) and planes.dtype == np.float32 and costs.dtype == np.float32
+        self._chk(self._f["get"](self._ctx, planes.ctypes.data, costs.ctypes.data, geom.ctypes.data if geom is not None else None), "get")
+
     def get_selected_views(self):
         s = np.empty((self.H, self.W), np.uint32)
         self._chk(self._f["get_selected_views"](self._ctx, s.ctypes.data), "get_selected_views")

@@ -33,6 +33,7 @@
 #include "pm_sky.hpp"
 #include "pm_kernels.hpp"
 #include "pm_coop.hpp"
+#include "pm_prior.hpp"
 
 using namespace pm;
 
@@ -178,6 +179,17 @@ struct DevBuf {
         if (p) (void)hipFree(p);
     }
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4); }
+    template <typename T>
+    T* as() const { return (T*)p; }
+};
+
+// pooled scratch buffer of one call: back to the pool on every return path (the caller synchronises the stream first)
+struct PoolBuf {
+    void* p = nullptr;
+    ~PoolBuf() {
+        if (p) (void)pool_free(p);
+    }
+    hipError_t alloc(size_t bytes) { return pool_malloc_bytes(&p, bytes ? bytes : 4); }
     template <typename T>
     T* as() const { return (T*)p; }
 };
@@ -557,6 +569,15 @@ int mpmvs_set_selected_views(mpmvs_ctx* c, const void* sel) {
     return 0;
 }
 
+int mpmvs_set_geom_costs(mpmvs_ctx* c, const void* geom) {
+    if (!c || !geom) return -1;
+    HIPCHK(c, enter_device(c->device));
+    if (!c->S.geom) return fail(c, -1, "set_views first");
+    HIPCHK(c, hipMemcpyAsync(c->S.geom, geom, (size_t)c->W * c->H * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int mpmvs_set_prior(mpmvs_ctx* c, const void* prior4, const void* mask) {
     if (!c) return -1;
     HIPCHK(c, enter_device(c->device));
@@ -879,6 +900,105 @@ int mpmvs_homography(mpmvs_ctx* c, const void* plane4, int v, void* H9) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// planar prior on the device (pm_prior.hpp)
+// ---------------------------------------------------------------------------
+int mpmvs_prior_vertices(mpmvs_ctx* c, int geom_rule, int* out_xy, int cap, int* n_out) {
+    if (!c || !out_xy || cap < 0 || !n_out) return -1;
+    HIPCHK(c, enter_device(c->device));
+    if (!c->S.costs) return fail(c, -1, "set_views first");
+    const int W = c->W, H = c->H;
+    const int ncx = (W + kPriorCell - 1) / kPriorCell, ncy = (H + kPriorCell - 1) / kPriorCell, ncells = ncx * ncy;
+    const int nb = (ncells + 255) / 256;
+    PoolBuf d_cnt, d_pts, d_sums, d_xy;
+    int rc = 0, total = 0;
+    if (d_cnt.alloc((size_t)ncells * 4) != hipSuccess || d_pts.alloc((size_t)ncells * 12) != hipSuccess || d_sums.alloc((size_t)(nb + 1) * 4) != hipSuccess ||
+        d_xy.alloc((size_t)cap * 8) != hipSuccess)
+        rc = -100;
+    if (!rc) {
+        hipLaunchKernelGGL(k_prior_cells, dim3(nb), dim3(256), 0, c->stream, c->S.costs, c->S.geom, W, H, geom_rule ? 1 : 0, ncx, ncells, d_cnt.as<int>(),
+                           d_pts.as<uint32_t>());
+        hipLaunchKernelGGL(k_prior_block_sums, dim3(nb), dim3(256), 0, c->stream, d_cnt.as<int>(), ncells, d_sums.as<int>());
+        hipLaunchKernelGGL(k_prior_scan, dim3(1), dim3(256), 0, c->stream, d_sums.as<int>(), nb);
+        hipLaunchKernelGGL(k_prior_scatter, dim3(nb), dim3(256), 0, c->stream, d_cnt.as<int>(), d_pts.as<uint32_t>(), ncells, d_sums.as<int>(), cap, d_xy.as<int>());
+        if (hipGetLastError() != hipSuccess) rc = -100;
+    }
+    if (!rc && hipMemcpyAsync(&total, d_sums.as<int>() + nb, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = -100;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = -100;
+    if (!rc && total > 0 &&
+        hipMemcpyAsync(out_xy, d_xy.p, (size_t)std::min(total, cap) * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+        rc = -100;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = -100;
+    if (rc) return fail(c, rc, "prior vertices failed on the device");
+    *n_out = total;
+    return 0;
+}
+
+int mpmvs_prior_from_triangles(mpmvs_ctx* c, const mpmvs_params* p, const int* tri_xy, int n) {
+    if (!c || !p || (n > 0 && !tri_xy) || n < 0) return -1;
+    HIPCHK(c, enter_device(c->device));
+    if (!c->S.planes) return fail(c, -1, "set_views first");
+    const int W = c->W, H = c->H;
+    for (int i = 0; i < 6 * n; i += 2)
+        if (tri_xy[i] < 0 || tri_xy[i] >= W || tri_xy[i + 1] < 0 || tri_xy[i + 1] >= H) return fail(c, -2, "triangle vertex outside the image");
+    const size_t wh = (size_t)W * H;
+    if (!c->d_prior) HIPCHK(c, pool_malloc(&c->d_prior, wh * 16));
+    if (!c->d_mask) HIPCHK(c, pool_malloc(&c->d_mask, wh * 4));
+    // task table: 64 consecutive p-rows of one triangle per wave (pm_prior.hpp); a triangle of longest edge L has at most
+    // floor(L) + 2 rows (the accumulated p passes 1 after L + 1 steps; the kernel's own p < 1 test is what decides)
+    std::vector<int> task_tri, task_row0;
+    task_tri.reserve((size_t)n + 1024);
+    task_row0.reserve((size_t)n + 1024);
+    for (int t = 0; t < n; ++t) {
+        const int* v = tri_xy + 6 * t;
+        const long long e01 = (long long)(v[0] - v[2]) * (v[0] - v[2]) + (long long)(v[1] - v[3]) * (v[1] - v[3]);
+        const long long e02 = (long long)(v[0] - v[4]) * (v[0] - v[4]) + (long long)(v[1] - v[5]) * (v[1] - v[5]);
+        const long long e12 = (long long)(v[2] - v[4]) * (v[2] - v[4]) + (long long)(v[3] - v[5]) * (v[3] - v[5]);
+        const int rows = (int)std::sqrt((double)std::max(e01, std::max(e02, e12))) + 3;
+        for (int r0 = 0; r0 < rows; r0 += 64) {
+            task_tri.push_back(t);
+            task_row0.push_back(r0);
+        }
+    }
+    const int n_tasks = (int)task_tri.size();
+    PoolBuf d_tri, d_pl, d_tt, d_tr;
+    int rc = 0;
+    if (d_tri.alloc((size_t)n * 24) != hipSuccess || d_pl.alloc((size_t)n * 16) != hipSuccess || d_tt.alloc((size_t)n_tasks * 4) != hipSuccess ||
+        d_tr.alloc((size_t)n_tasks * 4) != hipSuccess)
+        rc = -100;
+    if (!rc && n > 0 &&
+        (hipMemcpyAsync(d_tri.p, tri_xy, (size_t)n * 24, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+         hipMemcpyAsync(d_tt.p, task_tri.data(), (size_t)n_tasks * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+         hipMemcpyAsync(d_tr.p, task_row0.data(), (size_t)n_tasks * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess))
+        rc = -100;
+    if (!rc && hipMemsetAsync(c->d_mask, 0, wh * 4, c->stream) != hipSuccess) rc = -100;
+    if (!rc) {
+        if (n_tasks > 0)
+            hipLaunchKernelGGL(k_prior_raster, dim3((n_tasks + 3) / 4), dim3(256), 0, c->stream, d_tri.as<int>(), n_tasks, d_tt.as<int>(), d_tr.as<int>(), c->dP,
+                               c->S.planes, c->d_mask, d_pl.as<float4>());
+        hipLaunchKernelGGL(k_prior_finish, dim3((unsigned)((wh + 255) / 256)), dim3(256), 0, c->stream, c->dP, d_pl.as<float4>(), p->depth_min, p->depth_max,
+                           c->d_mask, c->d_prior);
+        if (hipGetLastError() != hipSuccess) rc = -100;
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = -100;  // the scratch buffers go back to the pool
+    if (rc) return fail(c, rc, "prior construction failed on the device");
+    c->S.prior = c->d_prior;
+    c->S.mask = c->d_mask;
+    c->have_prior = true;
+    return 0;
+}
+
+int mpmvs_get_prior(mpmvs_ctx* c, void* prior4, void* mask) {
+    if (!c) return -1;
+    HIPCHK(c, enter_device(c->device));
+    if (!c->have_prior) return fail(c, -5, "no prior installed");
+    const size_t wh = (size_t)c->W * c->H;
+    if (prior4) HIPCHK(c, hipMemcpyAsync(prior4, c->d_prior, wh * 16, hipMemcpyDeviceToHost, c->stream));
+    if (mask) HIPCHK(c, hipMemcpyAsync(mask, c->d_mask, wh * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int mpmvs_math(int fn, const void* in, void* out, int n) {
     if (fn < 0 || fn > 5 || n <= 0) return -1;
     (void)hipGetLastError();  // drop a stale error of an earlier call (see enter_device)
@@ -921,6 +1041,17 @@ static int fuse_impl(int device, int n, const mpmvs_camera* cams, const int* est
                      int use_dynamic, unsigned char* const* out_valid, float* const* out_points9, unsigned char* const* out_masks,
                      unsigned char** records, long long* n_records) {
     if (n <= 0 || (color_channels != 1 && color_channels != 3) || enter_device(device) != hipSuccess) return -1;
+    // every view id is used as an index below (host vectors, FuseView table, masks): reject lists that name images that do
+    // not exist before anything is launched (the reference looks ids up in a map, src/PatchMatch.cpp:306-312)
+    if (!src_off || !src_ids || src_off[0] != 0) return -2;
+    for (int i = 0; i < n; ++i) {
+        if (src_off[i + 1] < src_off[i]) return -2;
+        for (int k = src_off[i]; k < src_off[i + 1]; ++k)
+            if (src_ids[k] < 0 || src_ids[k] >= n) return -2;
+    }
+    // own stream: a fusion call must not stall the PatchMatch contexts other host threads drive on this device
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return -100;
     std::vector<FuseView> hv(n);
     std::vector<void*> to_free;
     auto dalloc = [&](size_t bytes) -> void* {
@@ -953,10 +1084,10 @@ static int fuse_impl(int device, int n, const mpmvs_camera* cams, const int* est
         d_valid[i] = (unsigned char*)dalloc(wh);
         d_out[i] = (float*)dalloc(wh * 36);
         if (!dd || !dn || !dg || (sky && sky[i] && !dsky) || !d_mask[i] || !d_next[i] || !d_valid[i] || !d_out[i]) { rc = -100; break; }
-        if (hipMemcpy(dd, depths[i], wh * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dn, normals[i], wh * 12, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(dg, colors[i], wh * color_channels, hipMemcpyHostToDevice) != hipSuccess || (dsky && hipMemcpy(dsky, sky[i], wh, hipMemcpyHostToDevice) != hipSuccess) ||
-            hipMemset(d_mask[i], 0, wh) != hipSuccess ||
-            hipMemset(d_next[i], 0, wh) != hipSuccess || hipMemset(d_valid[i], 0, wh) != hipSuccess || (!records && hipMemset(d_out[i], 0, wh * 36) != hipSuccess))
+        if (hipMemcpyAsync(dd, depths[i], wh * 4, hipMemcpyHostToDevice, st) != hipSuccess || hipMemcpyAsync(dn, normals[i], wh * 12, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(dg, colors[i], wh * color_channels, hipMemcpyHostToDevice, st) != hipSuccess || (dsky && hipMemcpyAsync(dsky, sky[i], wh, hipMemcpyHostToDevice, st) != hipSuccess) ||
+            hipMemsetAsync(d_mask[i], 0, wh, st) != hipSuccess ||
+            hipMemsetAsync(d_next[i], 0, wh, st) != hipSuccess || hipMemsetAsync(d_valid[i], 0, wh, st) != hipSuccess || (!records && hipMemsetAsync(d_out[i], 0, wh * 36, st) != hipSuccess))
             rc = -100;
         v.depth = dd;
         v.normal = dn;
@@ -974,62 +1105,62 @@ static int fuse_impl(int device, int n, const mpmvs_camera* cams, const int* est
     if (!rc) {
         d_views = (FuseView*)dalloc(sizeof(FuseView) * n);
         d_src = (int*)dalloc(sizeof(int) * (src_off[n] > 0 ? src_off[n] : 1));
-        if (!d_views || !d_src || hipMemcpy(d_views, hv.data(), sizeof(FuseView) * n, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(d_src, src_ids, sizeof(int) * src_off[n], hipMemcpyHostToDevice) != hipSuccess)
+        if (!d_views || !d_src || hipMemcpyAsync(d_views, hv.data(), sizeof(FuseView) * n, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(d_src, src_ids, sizeof(int) * src_off[n], hipMemcpyHostToDevice, st) != hipSuccess)
             rc = -100;
     }
     if (!rc && records) {
         d_blocks = (int*)dalloc(sizeof(int) * (max_blocks + 1));
         d_base = (long long*)dalloc(sizeof(long long));
         d_records = (unsigned char*)dalloc(total_px * kPlyRecord);  // upper bound: every pixel a point
-        if (!d_blocks || !d_base || !d_records || hipMemset(d_base, 0, sizeof(long long)) != hipSuccess) rc = -100;
+        if (!d_blocks || !d_base || !d_records || hipMemsetAsync(d_base, 0, sizeof(long long), st) != hipSuccess) rc = -100;
     }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     (void)hipEventCreate(&ev0);
     (void)hipEventCreate(&ev1);
-    (void)hipEventRecord(ev0, nullptr);
+    (void)hipEventRecord(ev0, st);
     for (int i = 0; i < n && !rc; ++i) {
         if (!estimate[i]) continue;
         const int b = src_off[i], num_ngb = src_off[i + 1] - b;
         if (num_ngb > kMaxFuseNgb) { rc = -2; break; }
         const dim3 grid((hv[i].w + 31) / 32, (hv[i].h + 7) / 8);
-        hipLaunchKernelGGL(k_fuse, grid, dim3(256), 0, nullptr, d_views, i, d_src + b, num_ngb, use_dynamic, d_valid[i], d_out[i]);
+        hipLaunchKernelGGL(k_fuse, grid, dim3(256), 0, st, d_views, i, d_src + b, num_ngb, use_dynamic, d_valid[i], d_out[i]);
         if (hipGetLastError() != hipSuccess) { rc = -100; break; }
         // the marks of image i become the masks the next image sees
         for (int j = 1; j < num_ngb; ++j) {
             const int s = src_ids[b + j];
-            if (hipMemcpyAsync(d_mask[s], d_next[s], (size_t)hv[s].w * hv[s].h, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) rc = -100;
+            if (hipMemcpyAsync(d_mask[s], d_next[s], (size_t)hv[s].w * hv[s].h, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = -100;
         }
         if (records && !rc) {
             const int wh = hv[i].w * hv[i].h, nb = (wh + 255) / 256;
-            hipLaunchKernelGGL(k_fuse_count, dim3(nb), dim3(256), 0, nullptr, d_valid[i], wh, d_blocks);
-            hipLaunchKernelGGL(k_fuse_scan, dim3(1), dim3(256), 0, nullptr, d_blocks, nb);
-            hipLaunchKernelGGL(k_fuse_scatter, dim3(nb), dim3(256), 0, nullptr, d_valid[i], d_out[i], wh, d_blocks, d_base, d_records);
-            hipLaunchKernelGGL(k_fuse_advance, dim3(1), dim3(1), 0, nullptr, d_base, d_blocks + nb);
+            hipLaunchKernelGGL(k_fuse_count, dim3(nb), dim3(256), 0, st, d_valid[i], wh, d_blocks);
+            hipLaunchKernelGGL(k_fuse_scan, dim3(1), dim3(256), 0, st, d_blocks, nb);
+            hipLaunchKernelGGL(k_fuse_scatter, dim3(nb), dim3(256), 0, st, d_valid[i], d_out[i], wh, d_blocks, d_base, d_records);
+            hipLaunchKernelGGL(k_fuse_advance, dim3(1), dim3(1), 0, st, d_base, d_blocks + nb);
             if (hipGetLastError() != hipSuccess) rc = -100;
         }
     }
-    (void)hipEventRecord(ev1, nullptr);
-    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -100;
+    (void)hipEventRecord(ev1, st);
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = -100;
     if (!rc) (void)hipEventElapsedTime(&g_fuse_kernel_ms, ev0, ev1);
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
     for (int i = 0; i < n && !rc; ++i) {
         const size_t wh = (size_t)hv[i].w * hv[i].h;
-        if ((out_valid && hipMemcpy(out_valid[i], d_valid[i], wh, hipMemcpyDeviceToHost) != hipSuccess) ||
-            (out_points9 && hipMemcpy(out_points9[i], d_out[i], wh * 36, hipMemcpyDeviceToHost) != hipSuccess) ||
-            (out_masks && hipMemcpy(out_masks[i], d_mask[i], wh, hipMemcpyDeviceToHost) != hipSuccess))
+        if ((out_valid && hipMemcpyAsync(out_valid[i], d_valid[i], wh, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+            (out_points9 && hipMemcpyAsync(out_points9[i], d_out[i], wh * 36, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+            (out_masks && hipMemcpyAsync(out_masks[i], d_mask[i], wh, hipMemcpyDeviceToHost, st) != hipSuccess))
             rc = -100;
     }
     if (!rc && records) {
         long long count = 0;
-        if (hipMemcpy(&count, d_base, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) rc = -100;
+        if ((hipMemcpyAsync(&count, d_base, sizeof(count), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st)) != hipSuccess) rc = -100;
         unsigned char* host = nullptr;
         if (!rc) {
             host = (unsigned char*)std::malloc(count > 0 ? (size_t)count * kPlyRecord : 1);
             if (!host) rc = -101;
         }
-        if (!rc && count > 0 && hipMemcpy(host, d_records, (size_t)count * kPlyRecord, hipMemcpyDeviceToHost) != hipSuccess) rc = -100;
+        if (!rc && count > 0 && hipMemcpyAsync(host, d_records, (size_t)count * kPlyRecord, hipMemcpyDeviceToHost, st) != hipSuccess) rc = -100;
         if (rc) {
             std::free(host);
         } else {
@@ -1037,8 +1168,9 @@ static int fuse_impl(int device, int n, const mpmvs_camera* cams, const int* est
             *n_records = count;
         }
     }
-    (void)hipDeviceSynchronize();  // also on an error path: nothing may still use what goes back to the pool
+    if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = -100;  // also on an error path: nothing may still use what goes back to the pool
     for (void* p : to_free) (void)pool_free(p);
+    (void)hipStreamDestroy(st);
     return rc;
 }
 
@@ -1071,28 +1203,33 @@ int mpmvs_sky_bilateral(int device, const unsigned char* bgr, const float* mask,
     const size_t wh = (size_t)height * width;
     unsigned char* d_img = nullptr;
     float *d_mask = nullptr, *d_out = nullptr;
+    hipStream_t st = nullptr;  // own stream: other contexts of this device keep running
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return -100;
     int rc = 0;
     if (pool_malloc(&d_img, wh * 3) != hipSuccess || pool_malloc(&d_mask, wh * 4) != hipSuccess || pool_malloc(&d_out, wh * 4) != hipSuccess) rc = -100;
-    if (!rc && (hipMemcpy(d_img, bgr, wh * 3, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_mask, mask, wh * 4, hipMemcpyHostToDevice) != hipSuccess)) rc = -100;
+    if (!rc && (hipMemcpyAsync(d_img, bgr, wh * 3, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(d_mask, mask, wh * 4, hipMemcpyHostToDevice, st) != hipSuccess))
+        rc = -100;
     if (!rc) {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         (void)hipEventCreate(&ev0);
         (void)hipEventCreate(&ev1);
-        (void)hipEventRecord(ev0, nullptr);
+        (void)hipEventRecord(ev0, st);
         const dim3 grid((width + kSkyTW - 1) / kSkyTW, (height + kSkyTH - 1) / kSkyTH);
-        hipLaunchKernelGGL(k_sky_bilateral, grid, dim3(256), 0, nullptr, d_img, d_mask, d_out, height, width);
+        hipLaunchKernelGGL(k_sky_bilateral, grid, dim3(256), 0, st, d_img, d_mask, d_out, height, width);
         if (hipGetLastError() != hipSuccess) rc = -100;
-        (void)hipEventRecord(ev1, nullptr);
-        if (!rc && hipDeviceSynchronize() != hipSuccess) rc = -100;
+        (void)hipEventRecord(ev1, st);
+        if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = -100;
         if (!rc) (void)hipEventElapsedTime(&g_sky_kernel_ms, ev0, ev1);
         (void)hipEventDestroy(ev0);
         (void)hipEventDestroy(ev1);
     }
-    if (!rc && hipMemcpy(out, d_out, wh * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = -100;
-    (void)hipDeviceSynchronize();
+    if (!rc && hipMemcpyAsync(out, d_out, wh * 4, hipMemcpyDeviceToHost, st) != hipSuccess) rc = -100;
+    if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = -100;  // also on an error path, before the buffers go back to the pool
     (void)pool_free(d_img);
     (void)pool_free(d_mask);
     (void)pool_free(d_out);
+    (void)hipStreamDestroy(st);
     return rc;
 }
 

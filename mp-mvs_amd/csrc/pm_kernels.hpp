@@ -62,10 +62,14 @@ __device__ constexpr int kNumDirs[8] = {12, 12, 12, 12, 10, 10, 10, 10};
 // rows per wave, block width and height (pixels) of a checkerboard launch on textures of format U8
 template <bool U8>
 constexpr int kWaveRows = U8 ? PM_WAVE_ROWS : PM_WAVE_ROWS_F32;
+// waves of a block: PM_BLOCK_WAVES_X side by side, 4 / PM_BLOCK_WAVES_X stacked
+#ifndef PM_BLOCK_WAVES_X
+#define PM_BLOCK_WAVES_X 1
+#endif
 template <bool U8>
-constexpr int kChkBlockW = 2 * (64 / kWaveRows<U8>);
+constexpr int kChkBlockW = 2 * (64 / kWaveRows<U8>) * PM_BLOCK_WAVES_X;
 template <bool U8>
-constexpr int kChkBlockH = 4 * kWaveRows<U8>;
+constexpr int kChkBlockH = (4 / PM_BLOCK_WAVES_X) * kWaveRows<U8>;
 
 // Blocks are dealt round-robin to the 8 XCDs (block b and b+8 share an L2):
 // renumber so that each XCD works through one contiguous run of the raster
@@ -86,8 +90,8 @@ PM_DEV bool checker_pixel(const ProblemDev& P, const LaunchArgs& a, int& x, int&
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     x0 = bx * kChkBlockW<U8>;
     y0 = by * kChkBlockH<U8>;
-    y = y0 + wv * kWaveRows<U8> + lane / kLanesPerRow;
-    x = x0 + 2 * (lane % kLanesPerRow);
+    y = y0 + (wv / PM_BLOCK_WAVES_X) * kWaveRows<U8> + lane / kLanesPerRow;
+    x = x0 + 2 * ((wv % PM_BLOCK_WAVES_X) * kLanesPerRow + lane % kLanesPerRow);
     x += (y + a.parity) & 1;
     return x < P.W && y < P.H && y < a.ylimit;
 }

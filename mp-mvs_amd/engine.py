@@ -21,6 +21,10 @@ _EXTRA = {
     "set_texture_format": (C.c_int, [_P, C.c_int]),
     "texture_format": (C.c_int, [_P]),
     "get_kernel_times": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "set_geom_costs": (C.c_int, [_P, _P]),
+    "prior_vertices": (C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
+    "prior_from_triangles": (C.c_int, [_P, C.POINTER(_abi.PatchMatchParams), _P, C.c_int]),
+    "get_prior": (C.c_int, [_P, _P, _P]),
     "eval_ncc_multi": (C.c_int, [_P, C.POINTER(_abi.PatchMatchParams), _P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_float)]),
 }
 ALL_SYMBOLS = ["mpmvs_" + n for n in list(_abi.SIGNATURES) + list(_EXTRA)] + ["mpmvs_fuse", "mpmvs_fuse_kernel_ms", "mpmvs_sky_bilateral", "mpmvs_sky_kernel_ms", "mpmvs_fuse_ply", "mpmvs_free"]
@@ -81,6 +85,35 @@ class HipPatchMatch(_abi.PatchMatchHandle):
         cnt = (C.c_int * 6)()
         self._chk(self._f["get_kernel_times"](self._ctx, ms, cnt), "get_kernel_times")
         return list(ms), list(cnt)
+
+    def set_geom_costs(self, geom):
+        import numpy as np
+        g = np.ascontiguousarray(geom, np.float32)
+        assert g.shape == (self.H, self.W)
+        self._chk(self._f["set_geom_costs"](self._ctx, g.ctypes.data), "set_geom_costs")
+
+    def prior_vertices(self, geom_rule):
+        """GetTriangulateVertices on the device -> [n, 2] int32 (x, y) in cell raster order"""
+        import numpy as np
+        cap = 3 * ((self.H + 4) // 5) * ((self.W + 4) // 5)
+        out = np.empty((cap, 2), np.int32)
+        n = C.c_int(0)
+        self._chk(self._f["prior_vertices"](self._ctx, 1 if geom_rule else 0, out.ctypes.data, cap, C.byref(n)), "prior_vertices")
+        return out[:n.value].copy()
+
+    def prior_from_triangles(self, params, tri_pts):
+        """raster + plane fit + depth-range test on the device for triangles [n][3][2] (all vertices inside the image);
+        installs the prior like set_prior"""
+        import numpy as np
+        t = np.ascontiguousarray(tri_pts, np.int32).reshape(-1, 6)
+        self._chk(self._f["prior_from_triangles"](self._ctx, C.byref(params), t.ctypes.data, len(t)), "prior_from_triangles")
+
+    def get_prior(self):
+        import numpy as np
+        prior = np.empty((self.H, self.W, 4), np.float32)
+        mask = np.empty((self.H, self.W), np.uint32)
+        self._chk(self._f["get_prior"](self._ctx, prior.ctypes.data, mask.ctypes.data), "get_prior")
+        return prior, mask
 
     def eval_ncc_multi(self, params, planes_cam, scale, mapping=0):
         """ComputeBilateralNCC of nh planes per pixel ([nh][H][W][4]) against every view -> ([nh][V][H][W], kernel ms);

@@ -20,6 +20,7 @@
 #define MPMVS_HOST_PATCHMATCH_H_
 
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -81,6 +82,11 @@ struct Image {
     float at(int r, int c, int k = 0) const { return data[((size_t)r * cols + c) * ch + k]; }
 };
 
+// Device residency of one Problem between the passes of the schedule: the context with the packed textures
+// of the Problem's views stays in HBM after Release() and the next ProcessProblem of the same Problem on the same device
+// adopts it instead of uploading the images again.  Opaque here; owned by the Problem's reference Scene.
+struct ProblemDeviceCache;
+
 // reference include/utility.h:17-26 (+ in-memory results instead of .dmb files)
 struct Scene {
     bool estimate = false;
@@ -92,7 +98,10 @@ struct Scene {
     Image normal;            // last estimated world normals    (normals.dmb)
     Image cost;              // last estimated costs            (costs.dmb)
     int max_image_size = 3200;
+    std::shared_ptr<ProblemDeviceCache> device_cache;  // see ProblemDeviceCache; dropped with the Scene or by ReleaseDeviceCaches
 };
+// gives the HBM held by cached Problem contexts back (end of a schedule)
+void ReleaseDeviceCaches(std::vector<Scene>& Scenes);
 
 // bilinear resize used by PatchMatchInit's "Adjust image scale" (reference src/PatchMatch.cpp:893-925)
 Image ResizeLinear(const Image& src, int new_cols, int new_rows);
@@ -115,7 +124,11 @@ class PatchMatchCUDA {
     std::vector<unsigned int> hostPlaneMask;
     PatchMatchParams params;
     std::string input_folder, output_folder;
+    Scene* ref_scene = nullptr;     // Scenes[ID] of PatchMatchInit: owner of the device cache
+    bool views_resident = false;    // the adopted context already holds this Problem's textures
+    bool host_state_valid = false;  // hostPlaneHypotheses / hostCosts mirror the device state
     void check(int rc, const char* what);
+    void fetch_host_state();        // the device-to-host block of Run() (reference src/PatchMatch.cu:1246-1251), on first use
 
    public:
     ~PatchMatchCUDA();
@@ -131,6 +144,9 @@ class PatchMatchCUDA {
     void AllocatePatchMatch();
     void CudaMemInit(Scene& scene);
     void CudaPlanarPriorInitialization(const std::vector<float4>& PlaneParams, const Image& masks);
+    // the same from the triangle list: rasterisation, plane fit and depth-range test of reference src/PatchMatch.cpp:554-595
+    // run on the device (mpmvs_prior_from_triangles); nothing but the triangles crosses PCIe
+    void CudaPlanarPriorInitialization(const std::vector<Triangle>& triangles);
     void Run();
 
     float GetDepthFromPlaneParam(const float4 plane_hypothesis, const int x, const int y);
@@ -141,7 +157,10 @@ class PatchMatchCUDA {
     const Image& GetReferenceImage();
     const Camera& GetReferenceCamera() const { return cameras[0]; }
     float4 GetPlaneHypothesis(const int index);
-    const float4* GetPlaneHypotheses() const { return hostPlaneHypotheses.data(); }  // the whole hostPlaneHypotheses array (no per-pixel call)
+    const float4* GetPlaneHypotheses() {  // the whole hostPlaneHypotheses array (no per-pixel call)
+        fetch_host_state();
+        return hostPlaneHypotheses.data();
+    }
     float GetCost(const int index);
     float GetGeomCost(const int index);
 

@@ -43,6 +43,41 @@ Image ResizeLinear(const Image& src, int new_cols, int new_rows) {
     return dst;
 }
 
+// ---------------------------------------------------------------------------
+// Problem contexts kept resident between passes.  A cached context is only adopted when device, view list (image buffers
+// and sizes) and cameras are the ones it was filled from.  MPMVS_CTX_CACHE_MB (default 65536, 0 = off) bounds the HBM held
+// this way; beyond it Release() destroys the context as the reference does.
+// ---------------------------------------------------------------------------
+#include <atomic>
+#include <mutex>
+struct ProblemDeviceCache {
+    mpmvs_ctx* ctx = nullptr;
+    int device = -1;
+    std::vector<const float*> image_data;
+    std::vector<Camera> cameras;
+    size_t bytes = 0;
+    static std::atomic<size_t>& held() {
+        static std::atomic<size_t> h(0);
+        return h;
+    }
+    ~ProblemDeviceCache() {
+        if (ctx) {
+            mpmvs_destroy(ctx);
+            held() -= bytes;
+        }
+    }
+};
+static size_t ctx_cache_cap() {
+    static const size_t cap = [] {
+        const char* e = std::getenv("MPMVS_CTX_CACHE_MB");
+        return (size_t)(e ? std::strtoull(e, nullptr, 10) : 65536ull) << 20;
+    }();
+    return cap;
+}
+void ReleaseDeviceCaches(std::vector<Scene>& Scenes) {
+    for (Scene& s : Scenes) s.device_cache.reset();
+}
+
 void PatchMatchCUDA::check(int rc, const char* what) {
     if (rc != 0) {
         std::cerr << what << " failed (" << rc << "): " << mpmvs_last_error(ctx) << std::endl;
@@ -103,6 +138,7 @@ void AdjustImageScale(Scene& s) {
 }
 
 void PatchMatchCUDA::PatchMatchInit(std::vector<Scene>& Scenes, const int ID) {
+    ref_scene = &Scenes[ID];
     images.clear();
     depths.clear();
     cameras.clear();
@@ -145,6 +181,21 @@ void PatchMatchCUDA::PatchMatchInit(std::vector<Scene>& Scenes, const int ID) {
 // reference src/PatchMatch.cpp:960-976
 void PatchMatchCUDA::AllocatePatchMatch() {
     const size_t wh = (size_t)cameras[0].width * cameras[0].height;
+    views_resident = false;
+    if (!ctx && ref_scene && ref_scene->device_cache) {
+        // adopt the context a previous pass left for this Problem, if it was filled from the same views
+        std::shared_ptr<ProblemDeviceCache> cached = std::move(ref_scene->device_cache);
+        ref_scene->device_cache.reset();
+        bool same = cached->ctx && cached->device == device && cached->image_data.size() == images.size() &&
+                    std::memcmp(cached->cameras.data(), cameras.data(), cameras.size() * sizeof(Camera)) == 0;
+        for (size_t i = 0; same && i < images.size(); ++i) same = cached->image_data[i] == images[i]->data.data();
+        if (same) {
+            ctx = cached->ctx;
+            cached->ctx = nullptr;
+            ProblemDeviceCache::held() -= cached->bytes;
+            views_resident = true;
+        }
+    }
     if (!ctx) ctx = mpmvs_create(device);
     if (!ctx) {
         std::cerr << "mpmvs_create failed: " << mpmvs_last_error(nullptr) << std::endl;
@@ -163,7 +214,8 @@ void PatchMatchCUDA::CudaMemInit(Scene& scene) {
         ptrs.push_back(images[i]->data.data());
         pitches.push_back((size_t)images[i]->cols * sizeof(float));
     }
-    check(mpmvs_set_views(ctx, num_img, cameras.data(), ptrs.data(), pitches.data()), "mpmvs_set_views");
+    if (!views_resident) check(mpmvs_set_views(ctx, num_img, cameras.data(), ptrs.data(), pitches.data()), "mpmvs_set_views");
+    host_state_valid = false;
     if (params.geom_consistency) {
         std::vector<const float*> dptr;
         std::vector<int> ws, hs;
@@ -211,11 +263,31 @@ void PatchMatchCUDA::CudaPlanarPriorInitialization(const std::vector<float4>& Pl
     tm.lap("  prior: mpmvs_set_prior");
 }
 
-// reference src/PatchMatch.cu:1188-1254: the launches live behind mpmvs_run, the
-// device-to-host copies (:1246-1251) behind mpmvs_get
+// reference src/PatchMatch.cpp:554-595 + :978-996 on the device
+void PatchMatchCUDA::CudaPlanarPriorInitialization(const std::vector<Triangle>& triangles) {
+    const Rect imageRC{0, 0, cameras[0].width, cameras[0].height};
+    std::vector<int> tri_xy;
+    tri_xy.reserve(triangles.size() * 6);
+    for (const Triangle& t : triangles)
+        if (imageRC.contains(t.pt1) && imageRC.contains(t.pt2) && imageRC.contains(t.pt3)) {  // reference :555
+            const int v[6] = {t.pt1.x, t.pt1.y, t.pt2.x, t.pt2.y, t.pt3.x, t.pt3.y};
+            tri_xy.insert(tri_xy.end(), v, v + 6);
+        }
+    check(mpmvs_prior_from_triangles(ctx, &params, tri_xy.data(), (int)(tri_xy.size() / 6)), "mpmvs_prior_from_triangles");
+}
+
+// reference src/PatchMatch.cu:1188-1254: the launches live behind mpmvs_run; the device-to-host copies that end the
+// reference's Run() (:1246-1251) are made when the host first asks for a value (fetch_host_state): between the two Run()
+// calls of a planar-prior Problem nothing has to leave HBM
 void PatchMatchCUDA::Run() {
     check(mpmvs_run(ctx, &params, seed), "mpmvs_run");
+    host_state_valid = false;
+}
+void PatchMatchCUDA::fetch_host_state() {
+    if (host_state_valid) return;
+    if (hostGeomCosts.empty() && params.geomPlanarPrior) hostGeomCosts.assign(hostCosts.size(), 0.0f);
     check(mpmvs_get(ctx, hostPlaneHypotheses.data(), hostCosts.data(), params.geomPlanarPrior && !hostGeomCosts.empty() ? hostGeomCosts.data() : nullptr), "mpmvs_get");
+    host_state_valid = true;
 }
 
 float PatchMatchCUDA::GetDepthFromPlaneParam(const float4 pl, const int x, const int y) {
@@ -227,11 +299,21 @@ float PatchMatchCUDA::GetMaxDepth() { return params.depth_max; }
 int PatchMatchCUDA::GetReferenceImageWidth() { return cameras[0].width; }
 int PatchMatchCUDA::GetReferenceImageHeight() { return cameras[0].height; }
 const Image& PatchMatchCUDA::GetReferenceImage() { return *images[0]; }
-float4 PatchMatchCUDA::GetPlaneHypothesis(const int index) { return hostPlaneHypotheses[index]; }
-float PatchMatchCUDA::GetCost(const int index) { return hostCosts[index]; }
-float PatchMatchCUDA::GetGeomCost(const int index) { return hostGeomCosts[index]; }
+float4 PatchMatchCUDA::GetPlaneHypothesis(const int index) {
+    fetch_host_state();
+    return hostPlaneHypotheses[index];
+}
+float PatchMatchCUDA::GetCost(const int index) {
+    fetch_host_state();
+    return hostCosts[index];
+}
+float PatchMatchCUDA::GetGeomCost(const int index) {
+    fetch_host_state();
+    return hostGeomCosts[index];
+}
 
 float4 PatchMatchCUDA::GetPriorPlaneParams(const Triangle triangle, int width) {
+    fetch_host_state();
     return mpmvs_host::PriorPlane(cameras[0], triangle, hostPlaneHypotheses.data(), width);
 }
 std::vector<Triangle> PatchMatchCUDA::DelaunayTriangulation(const Rect boundRC, const std::vector<Point>& points) {
@@ -241,17 +323,50 @@ std::vector<Triangle> PatchMatchCUDA::DelaunayTriangulation(const Rect boundRC, 
     }
     return mpmvs_host::Delaunay(boundRC, points);
 }
+// MPMVS_HOST_PRIOR=1: build the planar prior with the host implementation (planar_prior.cpp) instead of the device kernels
+// (pm_prior.hpp); both give the same bits (tests/test_prior_gpu.py)
+static bool host_prior_requested() {
+    static const bool on = std::getenv("MPMVS_HOST_PRIOR") != nullptr;
+    return on;
+}
 void PatchMatchCUDA::GetTriangulateVertices(std::vector<Point>& Vertices) {
-    mpmvs_host::TriangulateVertices(GetReferenceImageWidth(), GetReferenceImageHeight(), hostCosts.data(),
-                                    params.geomPlanarPrior ? hostGeomCosts.data() : nullptr, params.geomPlanarPrior, Vertices);
+    const int W = GetReferenceImageWidth(), H = GetReferenceImageHeight();
+    if (host_prior_requested()) {
+        fetch_host_state();
+        mpmvs_host::TriangulateVertices(W, H, hostCosts.data(), params.geomPlanarPrior ? hostGeomCosts.data() : nullptr, params.geomPlanarPrior, Vertices);
+        return;
+    }
+    const int cap = 3 * ((W + 4) / 5) * ((H + 4) / 5);
+    std::vector<int> xy((size_t)cap * 2);
+    int n = 0;
+    check(mpmvs_prior_vertices(ctx, params.geomPlanarPrior ? 1 : 0, xy.data(), cap, &n), "mpmvs_prior_vertices");
+    Vertices.resize((size_t)n);
+    for (int i = 0; i < n; ++i) Vertices[i] = Point(xy[2 * i], xy[2 * i + 1]);
 }
 
 // reference src/PatchMatch.cpp:1091-1139
 void PatchMatchCUDA::Release(std::vector<Scene>&, const int&) {
     StageTimer tm;
+    if (ctx && ref_scene && !cameras.empty()) {
+        // leave the context (textures, state) in HBM for the next pass over this Problem, within the cache budget
+        size_t bytes = 0;
+        for (const Camera& c : cameras) bytes += (size_t)c.width * c.height * 20;           // texture (<= 16 B / texel) + depth map
+        bytes += (size_t)cameras[0].width * cameras[0].height * 64;                        // planes, costs, masks, prior, padded image
+        if (ProblemDeviceCache::held() + bytes <= ctx_cache_cap()) {
+            auto keep = std::make_shared<ProblemDeviceCache>();
+            keep->ctx = ctx;
+            keep->device = device;
+            for (const Image* im : images) keep->image_data.push_back(im->data.data());
+            keep->cameras = cameras;
+            keep->bytes = bytes;
+            ProblemDeviceCache::held() += bytes;
+            ref_scene->device_cache = std::move(keep);
+            ctx = nullptr;
+        }
+    }
     if (ctx) mpmvs_destroy(ctx);
     ctx = nullptr;
-    tm.lap("  release: mpmvs_destroy");
+    tm.lap("  release: context");
     hostPlaneHypotheses.clear();
     hostCosts.clear();
     hostGeomCosts.clear();
@@ -292,12 +407,16 @@ void ProcessProblem(std::vector<Scene>& Scenes, const int ID, bool geom_consiste
         tm.lap("GetTriangulateVertices");
         const auto triangles = MP.DelaunayTriangulation(imageRC, Vertices);
         tm.lap("DelaunayTriangulation");
-        Image mask_tri;
-        std::vector<float4> planeParams_tri;
-        mpmvs_host::BuildPrior(MP.GetReferenceCamera(), width, height, triangles, MP.GetPlaneHypotheses(), MP.GetMinDepth(), MP.GetMaxDepth(),
-                               planeParams_tri, mask_tri);
-        tm.lap("BuildPrior");
-        MP.CudaPlanarPriorInitialization(planeParams_tri, mask_tri);
+        if (host_prior_requested()) {
+            Image mask_tri;
+            std::vector<float4> planeParams_tri;
+            mpmvs_host::BuildPrior(MP.GetReferenceCamera(), width, height, triangles, MP.GetPlaneHypotheses(), MP.GetMinDepth(), MP.GetMaxDepth(),
+                                   planeParams_tri, mask_tri);
+            tm.lap("BuildPrior (host)");
+            MP.CudaPlanarPriorInitialization(planeParams_tri, mask_tri);
+        } else {
+            MP.CudaPlanarPriorInitialization(triangles);  // raster, planes and mask on the device
+        }
         tm.lap("CudaPlanarPriorInit");
         MP.SetSeed(seed + 0x9E3779B97F4A7C15ull);  // second Run(): its own RNG streams
         MP.Run();

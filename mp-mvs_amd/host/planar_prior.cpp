@@ -22,60 +22,86 @@
 namespace mpmvs_host {
 
 // ---------------------------------------------------------------------------
-// vertices: per 5x5 cell, the pixel(s) with the most reliable depth
+// vertices: the image is cut into 5x5-pixel cells (smaller at the right / bottom border) and every cell may contribute its
+// most reliable pixels (SURVEY a-16).  Two selection rules:
+//   plain rule       the pixel of lowest cost, if that cost is a valid one (< 2) and below 0.1;
+//   geometric rule   the (up to) three pixels of lowest cost among those with cost < 1 and geometric cost < 0.4, in
+//                    ascending cost, as long as their cost stays below max(0.2, 0.85 * cell cost sum / (x_end * y_end)) --
+//                    the divisor is the product of the cell's absolute END coordinates, not its area (the reference's
+//                    formula, kept because it decides which vertices exist).
+// Ties keep the first pixel in raster order.  Both rules are applied by CellPicker below, one cell at a time, cells in
+// raster order, which is also the order of the vertex list.
 // ---------------------------------------------------------------------------
+namespace {
+struct CellPicker {
+    static constexpr int kCell = 5;
+    const float* cost;
+    const float* geom;
+    int width, height;
+
+    // lowest valid cost of the cell [x0, x1) x [y0, y1) and where it sits
+    bool best_pixel(int x0, int y0, int x1, int y1, Point& where, float& lowest) const {
+        lowest = 2.0f;
+        bool any = false;
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) {
+                const float c = cost[(size_t)y * width + x];
+                if (c < 2.0f && c < lowest) {
+                    lowest = c;
+                    where = Point(x, y);
+                    any = true;
+                }
+            }
+        return any;
+    }
+
+    // the three lowest costs among the geometrically consistent pixels of the cell, ascending; returns how many pass the
+    // cell's adaptive threshold
+    int best_three(int x0, int y0, int x1, int y1, Point (&where)[3]) const {
+        float low[3] = {2.0f, 2.0f, 2.0f};
+        float sum = 0.0f;
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) {
+                const size_t i = (size_t)y * width + x;
+                const float c = cost[i];
+                sum += c;
+                if (!(c < 1.0f && geom[i] < 0.4f && c < low[2])) continue;
+                // insert into the sorted triple; an equal cost stays behind the earlier pixel
+                int slot = 2;
+                while (slot > 0 && low[slot - 1] > c) {
+                    low[slot] = low[slot - 1];
+                    where[slot] = where[slot - 1];
+                    --slot;
+                }
+                low[slot] = c;
+                where[slot] = Point(x, y);
+            }
+        const float scaled = (float)((double)(sum / (float)(y1 * x1)) * 0.85);
+        const float limit = scaled > 0.2f ? scaled : 0.2f;
+        int n = 0;
+        while (n < 3 && low[n] < limit) ++n;
+        return n;
+    }
+};
+}  // namespace
+
 void TriangulateVertices(int width, int height, const float* costs, const float* geom_costs, bool geomPlanarPrior,
                          std::vector<Point>& Vertices) {
     Vertices.clear();
-    const int step_size = 5;
-    for (int row = 0; row < height; row += step_size) {
-        for (int col = 0; col < width; col += step_size) {
-            const int c_bound = std::min(width, col + step_size);
-            const int r_bound = std::min(height, row + step_size);
-            if (!geomPlanarPrior) {
-                float min_cost = 2.0f;
-                Point best;
-                for (int r = row; r < r_bound; ++r)
-                    for (int c = col; c < c_bound; ++c) {
-                        const float cost = costs[(size_t)r * width + c];
-                        if (cost < 2.0f && min_cost > cost) {
-                            best = Point(c, r);
-                            min_cost = cost;
-                        }
-                    }
-                if (min_cost < 0.1f) Vertices.push_back(best);
+    const CellPicker pick{costs, geom_costs, width, height};
+    for (int y0 = 0; y0 < height; y0 += CellPicker::kCell)
+        for (int x0 = 0; x0 < width; x0 += CellPicker::kCell) {
+            const int x1 = std::min(width, x0 + CellPicker::kCell), y1 = std::min(height, y0 + CellPicker::kCell);
+            if (geomPlanarPrior) {
+                Point p[3];
+                const int n = pick.best_three(x0, y0, x1, y1, p);
+                Vertices.insert(Vertices.end(), p, p + n);
             } else {
-                float minCosts[3] = {2.0f, 2.0f, 2.0f};
-                Point pts[3];
-                float cost_sum = 0.0f;
-                for (int r = row; r < r_bound; ++r)
-                    for (int c = col; c < c_bound; ++c) {
-                        const size_t idx = (size_t)r * width + c;
-                        const float cost = costs[idx];
-                        cost_sum += cost;
-                        if (cost < 1.0f && geom_costs[idx] < 0.4f && cost < minCosts[2]) {
-                            minCosts[2] = cost;
-                            pts[2] = Point(c, r);
-                            for (int i = 1; i >= 0; --i) {
-                                if (minCosts[i] <= minCosts[i + 1]) break;
-                                std::swap(minCosts[i], minCosts[i + 1]);
-                                std::swap(pts[i], pts[i + 1]);
-                            }
-                        }
-                    }
-                // the divisor is the product of the absolute bounds, not the cell
-                // area (reference src/PatchMatch.cpp:841, kept as is)
-                cost_sum = (float)(cost_sum / (float)(r_bound * c_bound) * 0.85);
-                const float thresh_cost = std::max(cost_sum, 0.2f);
-                for (int i = 0; i < 3; ++i) {
-                    if (minCosts[i] < thresh_cost)
-                        Vertices.push_back(pts[i]);
-                    else
-                        break;
-                }
+                Point p;
+                float lowest;
+                if (pick.best_pixel(x0, y0, x1, y1, p, lowest) && lowest < 0.1f) Vertices.push_back(p);
             }
         }
-    }
 }
 
 // ---------------------------------------------------------------------------

@@ -70,60 +70,100 @@ int writeNormalDmb(const std::string file_path, const Image& normal) { return wr
 // ---------------------------------------------------------------------------
 // cameras and the Problem list
 // ---------------------------------------------------------------------------
-Camera ReadCamera(const std::string& cam_path) {
-    Camera camera{};
-    std::ifstream file(cam_path);
-    if (!file.is_open()) {
-        std::cout << "can not open file in path:   " << cam_path << std::endl;
+// `<id>_cam.txt` (MVSNet layout): the keyword "extrinsic" followed by a 4x4 world-to-camera matrix [R t; 0 0 0 1],
+// the keyword "intrinsic" followed by the 3x3 K, then "depth_min interval depth_num depth_max".  The camera centre
+// C = -R^T t is derived here as the reference does when it loads a camera.
+namespace {
+struct CamTokens {
+    std::ifstream in;
+    std::string path;
+    void expect_word(const char* word) {
+        std::string w;
+        if (!(in >> w) || w != word) die("missing section '" + std::string(word) + "'");
+    }
+    float number() {
+        float v;
+        if (!(in >> v)) die("number expected");
+        return v;
+    }
+    [[noreturn]] void die(const std::string& why) const {
+        std::cout << "camera file " << path << ": " << why << std::endl;
         exit(1);
     }
-    std::string line;
-    file >> line;  // "extrinsic"
-    for (int i = 0; i < 3; ++i) file >> camera.R[3 * i + 0] >> camera.R[3 * i + 1] >> camera.R[3 * i + 2] >> camera.t[i];
-    float tmp[4];
-    file >> tmp[0] >> tmp[1] >> tmp[2] >> tmp[3];
-    file >> line;  // "intrinsic"
-    for (int i = 0; i < 3; ++i) file >> camera.K[3 * i + 0] >> camera.K[3 * i + 1] >> camera.K[3 * i + 2];
-    // C = -R^T t (reference src/PatchMatch.cpp:134-136)
-    camera.C[0] = -(camera.R[0] * camera.t[0] + camera.R[3] * camera.t[1] + camera.R[6] * camera.t[2]);
-    camera.C[1] = -(camera.R[1] * camera.t[0] + camera.R[4] * camera.t[1] + camera.R[7] * camera.t[2]);
-    camera.C[2] = -(camera.R[2] * camera.t[0] + camera.R[5] * camera.t[1] + camera.R[8] * camera.t[2]);
-    float depth_num, interval;
-    file >> camera.depth_min >> interval >> depth_num >> camera.depth_max;
-    return camera;
+};
+}  // namespace
+
+Camera ReadCamera(const std::string& cam_path) {
+    CamTokens tk;
+    tk.path = cam_path;
+    tk.in.open(cam_path);
+    if (!tk.in.is_open()) tk.die("cannot be opened");
+    Camera cam{};
+    tk.expect_word("extrinsic");
+    for (int row = 0; row < 4; ++row)
+        for (int col = 0; col < 4; ++col) {
+            const float v = tk.number();
+            if (row < 3 && col < 3) cam.R[3 * row + col] = v;
+            if (row < 3 && col == 3) cam.t[row] = v;
+        }
+    tk.expect_word("intrinsic");
+    for (int k = 0; k < 9; ++k) cam.K[k] = tk.number();
+    for (int k = 0; k < 3; ++k) cam.C[k] = -(cam.R[k] * cam.t[0] + cam.R[3 + k] * cam.t[1] + cam.R[6 + k] * cam.t[2]);
+    cam.depth_min = tk.number();
+    (void)tk.number();  // depth interval
+    (void)tk.number();  // number of depth planes
+    cam.depth_max = tk.number();
+    return cam;
 }
 
+// `pair.txt`: the number of entries, then per entry the reference image id and a line "n id_0 score_0 ...
+// id_{n-1} score_{n-1}" of candidate source views, best first.  Scene k describes image k: ids that pair.txt skips get a
+// placeholder that is never estimated.  A candidate is kept when its score is positive and its POSITION in the list is
+// below maxSourceImageNum (the position counts dropped candidates too, as in the reference); srcID[0] is the image itself.
+// An id outside [0, number of scenes) -- a malformed file; the reference would index out of bounds -- is dropped with a
+// warning, so that every srcID can be used as an index by the passes and by the fusion.
 void GenerateSampleList(const std::string& input_folder, int maxSourceImageNum, int maxImageSize, std::vector<Scene>& Scenes) {
     Scenes.clear();
-    const std::string path = input_folder + "/pair.txt";
-    std::ifstream file(path);
-    if (!file.is_open()) {
-        std::cout << "can not open file in path:   " << path << std::endl;
+    const std::string list_path = input_folder + "/pair.txt";
+    std::ifstream in(list_path);
+    if (!in.is_open()) {
+        std::cout << "view list " << list_path << " cannot be opened" << std::endl;
         exit(1);
     }
-    int num_images;
-    file >> num_images;
-    for (int i = 0; i < num_images; ++i) {
-        Scene scene;
-        scene.max_image_size = maxImageSize;
-        file >> scene.refID;
-        scene.srcID.push_back(scene.refID);
-        while (scene.refID > (int)Scenes.size()) {  // ids missing from pair.txt become placeholders
-            Scene temp;
-            temp.estimate = false;
-            Scenes.push_back(temp);
+    int entries = 0;
+    in >> entries;
+    for (int e = 0; e < entries; ++e) {
+        int ref = -1, listed = 0;
+        if (!(in >> ref >> listed) || ref < (int)Scenes.size()) {
+            std::cout << "view list " << list_path << ": entry " << e << " is malformed (ids must ascend)" << std::endl;
+            exit(1);
         }
-        int num_src_images;
-        file >> num_src_images;
-        for (int j = 0; j < num_src_images; ++j) {
-            int id;
-            float score;
-            file >> id >> score;
-            if (score <= 0.0f) continue;
-            if (j < maxSourceImageNum) scene.srcID.push_back(id);
+        Scene placeholder;
+        placeholder.estimate = false;
+        Scenes.resize((size_t)ref, placeholder);
+        Scene sc;
+        sc.max_image_size = maxImageSize;
+        sc.refID = ref;
+        sc.estimate = listed != 0;
+        sc.srcID.assign(1, ref);
+        for (int pos = 0; pos < listed; ++pos) {
+            int id = -1;
+            float score = 0.0f;
+            in >> id >> score;
+            if (score > 0.0f && pos < maxSourceImageNum) sc.srcID.push_back(id);
         }
-        scene.estimate = num_src_images != 0;
-        Scenes.push_back(scene);
+        Scenes.push_back(sc);
+    }
+    const int n = (int)Scenes.size();
+    for (Scene& sc : Scenes) {
+        std::vector<int> kept;
+        for (int id : sc.srcID) {
+            if (id >= 0 && id < n)
+                kept.push_back(id);
+            else
+                std::cerr << "view list " << list_path << ": image " << sc.refID << " names source " << id << ", which does not exist; dropped" << std::endl;
+        }
+        sc.srcID.swap(kept);
     }
 }
 
@@ -344,12 +384,12 @@ int RunFolderJacobi(const std::string& input_folder, int max_src, int max_image_
     auto run_pass = [&](bool geom, bool pp, uint64_t pass_seed) {
         std::vector<ProblemResult> results(n);
         std::atomic<size_t> next(0);
-        auto work = [&](int worker) {
-            const int device = devices[worker % devices.size()];
+        auto work = [&](int) {
             for (;;) {
                 const size_t k = next.fetch_add(1);
                 if (k >= todo.size()) return;
                 const int i = todo[k];
+                const int device = devices[k % devices.size()];  // fixed per Problem: its context stays resident there between passes
                 ProcessProblem(Scenes, i, geom, pp, pass_seed + (uint64_t)i, device, max_scale, &results[i]);
                 const std::string folder = out + "/2333_" + id8(Scenes[i].refID);
                 mkdir(folder.c_str(), 0777);

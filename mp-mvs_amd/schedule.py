@@ -49,6 +49,7 @@ class SceneScheduler:
         for im in images:
             assert im.shape == (self.H, self.W), "the all-gather assumes equally sized depth maps"
         self.device_tensors = device_tensors
+        self.fetch_results = True   # device mode only: False leaves every pass's maps in HBM (bench.py --workload cfg4)
         self.handles = {}
         for i in self.owned:
             h = make_handle()
@@ -73,21 +74,31 @@ class SceneScheduler:
         p = self._params(i, geom, planar)
         if geom:
             self._attach_source_depths(i, h)
-            planes, costs, _ = self.results[i]
-            h.set_state(planes, costs)
+            if not self.device_tensors:                 # device mode: the context still holds its own previous result
+                planes, costs, _ = self.results[i]
+                h.set_state(planes, costs)
         h.run(p, seed)
         if planar:                                      # reference src/PatchMatch.cpp:532-607
-            planes, costs, g = h.get(geom=True)
             geom_pp = bool(p.geomPlanarPrior)
-            cam = self.cams[i]
-            prior, mask, ntri = hostlib.build_prior(cam, planes, costs, g if geom_pp else None, geom_pp, p.depth_min, p.depth_max)
-            if ntri <= 0:
-                raise RuntimeError("No Point to Triangulate!")
-            h.set_prior(prior, mask)
+            if hasattr(h, "prior_vertices"):
+                # HIP context: vertex selection, rasterisation, plane fit and range test run on the device; only the vertex
+                # and triangle lists cross PCIe, the Delaunay triangulation is the host's (bit-identical to the host path)
+                verts = h.prior_vertices(geom_pp)
+                if len(verts) == 0:
+                    raise RuntimeError("No Point to Triangulate!")
+                h.prior_from_triangles(p, hostlib.delaunay(self.W, self.H, verts))
+            else:
+                planes, costs, g = h.get(geom=True)
+                prior, mask, ntri = hostlib.build_prior(self.cams[i], planes, costs, g if geom_pp else None, geom_pp, p.depth_min, p.depth_max)
+                if ntri <= 0:
+                    raise RuntimeError("No Point to Triangulate!")
+                h.set_prior(prior, mask)
             p.planar_prior = True
             p.geom_consistency = False
             p.max_iterations = 3
             h.run(p, (seed + PRIOR_SEED_OFFSET) & 0xFFFFFFFFFFFFFFFF)
+        if self.device_tensors and not self.fetch_results:
+            return None                                 # maps stay in HBM; fetch() brings them to the host on demand
         planes, costs, g = h.get(geom=True)
         return planes, costs, g
 
@@ -135,14 +146,29 @@ class SceneScheduler:
     # -- the pass schedule of reference src/main.cpp:20-41 ----------------------
     def run(self, geom_iterations=2, planar_prior=True, geom_planar_prior=True, seed=12345):
         planar0 = (not geom_planar_prior) and planar_prior
-        self.results = self._pass(lambda i: self._process(i, False, planar0, seed + i))
-        self._exchange()
+        self._timed_pass("photometric", lambda i: self._process(i, False, planar0, seed + i))
         for g in range(geom_iterations):
             planar = bool(geom_planar_prior and g != geom_iterations - 1)
             # Jacobi: nothing of pass g is visible during pass g (results swapped afterwards)
-            self.results = self._pass(lambda i, g=g, planar=planar: self._process(i, True, planar, seed + 100003 * (g + 1) + i))
-            self._exchange()
+            self._timed_pass("geometric" + (" + planar prior" if planar else ""),
+                             lambda i, g=g, planar=planar: self._process(i, True, planar, seed + 100003 * (g + 1) + i))
         return self.results
+
+    def _timed_pass(self, name, fn):
+        """one pass over the owned Problems, then the exchange (= barrier); if `self.timing` is a list, the wall times of
+        both halves on this rank are appended to it"""
+        import time
+        t0 = time.perf_counter()
+        self.results = self._pass(fn)
+        t1 = time.perf_counter()
+        self._exchange()
+        t2 = time.perf_counter()
+        if isinstance(getattr(self, "timing", None), list):
+            self.timing.append({"pass": name, "compute_ms": round((t1 - t0) * 1e3, 2), "exchange_ms": round((t2 - t1) * 1e3, 2)})
+
+    def fetch(self):
+        """results of the last pass on the host: problem -> (planes, costs, geom costs)"""
+        return {i: self.handles[i].get(geom=True) for i in self.owned}
 
     def _pass(self, fn):
         if self.workers == 1 or len(self.owned) <= 1:

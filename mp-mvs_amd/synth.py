@@ -88,18 +88,33 @@ def render_view(width, height, K, R, Cc, seed, fs):
     return img.astype(np.float32), d.astype(np.float32)
 
 
-def make_scene(width, height, centers, seed=SCENE_SEED, rot_deg=2.0, depth_min=3.0, depth_max=8.0, quantize=False, focal_jitter=0.0):
+def make_view(width, height, Cc, R, Kv, seed, depth_min, depth_max, quantize):
+    """one view of make_scene: camera with rotation R at centre Cc, rendered with the fp32-rounded camera"""
+    fs = width / 1600.0
+    t = -R @ Cc
+    cam = make_camera(Kv, R, t, height, width, depth_min, depth_max)
+    # render with the fp32-rounded camera so images and Camera agree
+    Kf = np.array(cam.K, np.float64).reshape(3, 3)
+    Rf = np.array(cam.R, np.float64).reshape(3, 3)
+    Cf = np.array(cam.C, np.float64)
+    img, gt = render_view(width, height, Kf, Rf, Cf, seed, fs)
+    if quantize:
+        img = np.rint(img).astype(np.float32)
+    return View(cam, img, gt, Kf, Rf, Cf)
+
+
+def make_scene(width, height, centers, seed=SCENE_SEED, rot_deg=2.0, depth_min=3.0, depth_max=8.0, quantize=False, focal_jitter=0.0, only=None):
     """Cameras at `centers` (N x 3 world positions), fx = fy = 0.9 W, principal
     point at the image centre; camera 0..N-1 in the order given.  quantize=True
     rounds the images to integers 0..255 like an 8-bit camera image (what the
-    reference feeds its textures: imread(GRAYSCALE) -> CV_32F, src/PatchMatch.cpp:877-882)."""
+    reference feeds its textures: imread(GRAYSCALE) -> CV_32F, src/PatchMatch.cpp:877-882).
+    only: render just these view indices (the others are None) -- every view still gets the rotation and
+    intrinsics it has in the full scene (the random draws are made for all views in order)."""
     rng = np.random.default_rng(seed)
-    fs = width / 1600.0
     K = np.array([[0.9 * width, 0, width / 2.0], [0, 0.9 * width, height / 2.0], [0, 0, 1.0]])
     sc = Scene(width, height)
-    for Cc in np.asarray(centers, np.float64):
+    for i, Cc in enumerate(np.asarray(centers, np.float64)):
         R = _small_rotation(rng, rot_deg)
-        t = -R @ Cc
         Kv = K.copy()
         if focal_jitter > 0:   # per-view intrinsics: different focal lengths and principal points
             f = rng.uniform(1.0 - focal_jitter, 1.0 + focal_jitter, 2)
@@ -107,15 +122,7 @@ def make_scene(width, height, centers, seed=SCENE_SEED, rot_deg=2.0, depth_min=3
             Kv[1, 1] *= f[1]
             Kv[0, 2] += rng.uniform(-0.05, 0.05) * width
             Kv[1, 2] += rng.uniform(-0.05, 0.05) * height
-        cam = make_camera(Kv, R, t, height, width, depth_min, depth_max)
-        # render with the fp32-rounded camera so images and Camera agree
-        Kf = np.array(cam.K, np.float64).reshape(3, 3)
-        Rf = np.array(cam.R, np.float64).reshape(3, 3)
-        Cf = np.array(cam.C, np.float64)
-        img, gt = render_view(width, height, Kf, Rf, Cf, seed, fs)
-        if quantize:
-            img = np.rint(img).astype(np.float32)
-        sc.views.append(View(cam, img, gt, Kf, Rf, Cf))
+        sc.views.append(make_view(width, height, Cc, R, Kv, seed, depth_min, depth_max, quantize) if only is None or i in only else None)
     return sc
 
 

@@ -80,3 +80,16 @@ def test_fuse_ply_records_equal_uncompacted_path(pm, oracle, engine, use_sky):
     assert all(np.array_equal(a, b) for a, b in zip(masks, masks2))
     rec0, _ = fusion.fuse_ply(cams, [False] * 6, depths, normals, cols, neigh)
     assert rec0.shape == (0, 27)
+
+
+def test_fusion_rejects_view_ids_that_do_not_exist(pm, engine):
+    """a malformed pair.txt can name an image past the last one: mpmvs_fuse must refuse it (rc -2) before it indexes anything"""
+    fusion = importlib.import_module("mp-mvs_amd.fusion")
+    sc, cams, depths, normals, grays, neigh = _scene(pm, size=(64, 48))
+    for bad in (6, -1, 1 << 20):
+        broken = [list(s) for s in neigh]
+        broken[3][1] = bad
+        with pytest.raises(RuntimeError, match=r"\(-2\)"):
+            fusion.fuse(cams, [True] * 6, depths, normals, grays, broken)
+    cg, _, _ = fusion.fuse(cams, [True] * 6, depths, normals, grays, neigh)   # and the device is still usable afterwards
+    assert len(cg) > 100

@@ -299,3 +299,10 @@ def test_ply_layout(hostlib, tmp_path):
     assert len(body) == 2 * 27
     assert np.frombuffer(body[:24], np.float32).tolist() == [1, 2, 3, 0, 0, -1] and list(body[24:27]) == [30, 20, 10]   # red green blue
     assert np.frombuffer(body[27:39], np.float32).tolist() == [0, 0, 0]                                               # non-finite -> origin
+
+
+def test_pair_list_drops_ids_that_do_not_exist(hostlib, tmp_path):
+    """pair.txt naming a source view beyond the last image (malformed): the id is dropped, nothing indexes out of bounds"""
+    (tmp_path / "pair.txt").write_text("3\n0\n2 1 10.0 7 9.0\n1\n3 0 5.0 2 4.0 -3 8.0\n2\n1 1 0.0\n")
+    got = hostlib.sample_list(str(tmp_path))
+    assert got == [(True, 0, [0, 1]), (True, 1, [1, 0, 2]), (True, 2, [2])]

@@ -43,21 +43,24 @@ def _worker(rank, world, port, kw, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kw", [dict(geom_iterations=2, planar_prior=True, geom_planar_prior=True, seed=777),
-                                dict(geom_iterations=1, planar_prior=False, geom_planar_prior=False, seed=5)])
-def test_two_ranks_equal_one_rank(tmp_path, kw):
+@pytest.mark.parametrize("world,kw", [(2, dict(geom_iterations=2, planar_prior=True, geom_planar_prior=True, seed=777)),
+                                      (2, dict(geom_iterations=1, planar_prior=False, geom_planar_prior=False, seed=5)),
+                                      # 6 Problems over 4 ranks: uneven shards (2, 2, 1, 1), padded all-gather slots
+                                      (4, dict(geom_iterations=2, planar_prior=True, geom_planar_prior=True, seed=31))])
+def test_ranks_equal_one_rank(tmp_path, world, kw):
     import torch.multiprocessing as mp
     sched = importlib.import_module("mp-mvs_amd.schedule")
     assert sched.owned_problems(6, 0, 2) == [0, 2, 4] and sched.owned_problems(6, 1, 2) == [1, 3, 5]
+    assert [sched.owned_problems(6, r, 4) for r in range(4)] == [[0, 4], [1, 5], [2], [3]]
     ref, ref_depths = _run(0, 1, None, kw)
     assert sorted(ref) == list(range(NX * NY))
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, kw, str(tmp_path)), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, kw, str(tmp_path)), nprocs=world, join=True)
     seen = set()
-    for rank in range(2):
+    for rank in range(world):
         z = np.load(os.path.join(str(tmp_path), f"rank{rank}.npz"))
         assert np.array_equal(z["all_depths"], ref_depths), "every rank holds every depth map after the barrier"
-        for i in sched.owned_problems(NX * NY, rank, 2):
+        for i in sched.owned_problems(NX * NY, rank, world):
             assert np.array_equal(z[f"planes{i}"], ref[i][0]) and np.array_equal(z[f"costs{i}"], ref[i][1]), f"problem {i}"
             seen.add(i)
     assert seen == set(range(NX * NY))

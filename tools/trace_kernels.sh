@@ -1,0 +1,13 @@
+#!/bin/bash
+# rocprofv3 kernel trace of one python command, summarised per kernel (template arguments kept):
+#   tools/trace_kernels.sh <tag> tools/time_process_problem.py     -> gpurun_out/trace_<tag>/summary.txt
+# The program itself follows `--` (no env / bash -c hop: the profiler's preloaded library has initialised the GPU by then).
+set -o pipefail
+TAG=$1; shift
+cd ${GRAFT_REPO_ROOT:?}
+export OUT=$PWD/gpurun_out/trace_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 "$@" > $OUT/stdout.txt 2> $OUT/stderr.txt
+python3 tools/summarize_trace.py $OUT/trace > $OUT/summary.txt
+cat $OUT/summary.txt
