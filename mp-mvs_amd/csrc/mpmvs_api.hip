@@ -627,12 +627,20 @@ static dim3 checker_grid(const mpmvs_ctx* c, const LaunchArgs& a) {
     const int rows = c->H < a.ylimit ? c->H : a.ylimit;
     return dim3(((c->W + kChkBlockW<U8> - 1) / kChkBlockW<U8>) * ((rows + kChkBlockH<U8> - 1) / kChkBlockH<U8>));
 }
+// The per-view arrays of the update kernel (8 x V candidate costs and four V-vectors, in scratch) are sized by a template
+// bound on the number of source views: buckets of 8 keep that scratch and the register pressure around it proportional to the
+// Problem (the shipped configuration allows 20 views, reference config/config.yaml:19; the hard limit is 32, ref .cu:500).
 template <bool GEOM, bool PRIOR, bool U8>
 static void launch_update2(mpmvs_ctx* c, const LaunchArgs& a) {
     const dim3 grid = checker_grid<U8>(c, a);
     const size_t lds = ncc_lds_bytes(kChkBlockW<U8>, kChkBlockH<U8>, a.scale);
-    if (c->hP.V <= 8)
+    const int V = c->hP.V;
+    if (V <= 8)
         hipLaunchKernelGGL((k_update<GEOM, PRIOR, 8, U8>), grid, dim3(256), lds, c->stream, c->dP, c->S, a);
+    else if (V <= 16)
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 16, U8>), grid, dim3(256), lds, c->stream, c->dP, c->S, a);
+    else if (V <= 24)
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 24, U8>), grid, dim3(256), lds, c->stream, c->dP, c->S, a);
     else
         hipLaunchKernelGGL((k_update<GEOM, PRIOR, kMaxViews, U8>), grid, dim3(256), lds, c->stream, c->dP, c->S, a);
 }
@@ -671,16 +679,27 @@ static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int 
     const dim3 grid_dense((c->W + 15) / 16, (c->H + 15) / 16);
     const dim3 grid_chk = checker_grid<true>(c, a);  // k_filter (checker_pixel<true>)
     switch (kind) {
-        case MPMVS_KIND_INIT:
-            if (c->hP.V <= 8 && c->all_u8)
-                hipLaunchKernelGGL((k_init<8, true>), grid_dense, blk, ncc_lds_bytes(16, 16, a.scale), c->stream, c->dP, c->S, a);
-            else if (c->hP.V <= 8)
-                hipLaunchKernelGGL((k_init<8, false>), grid_dense, blk, ncc_lds_bytes(16, 16, a.scale), c->stream, c->dP, c->S, a);
-            else if (c->all_u8)
-                hipLaunchKernelGGL((k_init<kMaxViews, true>), grid_dense, blk, ncc_lds_bytes(16, 16, a.scale), c->stream, c->dP, c->S, a);
+        case MPMVS_KIND_INIT: {
+            const size_t lds = ncc_lds_bytes(16, 16, a.scale);
+            const int V = c->hP.V;
+#define PM_LAUNCH_INIT(MV)                                                                                                  \
+    do {                                                                                                                    \
+        if (c->all_u8)                                                                                                      \
+            hipLaunchKernelGGL((k_init<MV, true>), grid_dense, blk, lds, c->stream, c->dP, c->S, a);                        \
+        else                                                                                                                \
+            hipLaunchKernelGGL((k_init<MV, false>), grid_dense, blk, lds, c->stream, c->dP, c->S, a);                       \
+    } while (0)
+            if (V <= 8)
+                PM_LAUNCH_INIT(8);
+            else if (V <= 16)
+                PM_LAUNCH_INIT(16);
+            else if (V <= 24)
+                PM_LAUNCH_INIT(24);
             else
-                hipLaunchKernelGGL((k_init<kMaxViews, false>), grid_dense, blk, ncc_lds_bytes(16, 16, a.scale), c->stream, c->dP, c->S, a);
+                PM_LAUNCH_INIT(kMaxViews);
+#undef PM_LAUNCH_INIT
             break;
+        }
         case MPMVS_KIND_BLACK:
         case MPMVS_KIND_RED:
             if (p->geom_consistency)
@@ -831,7 +850,7 @@ static int eval_ncc_impl(mpmvs_ctx* c, const mpmvs_params* p, const void* planes
         const int G = mapping <= 2 ? 4 : 8, pix = 256 / G, bh = pix / 8;
         const dim3 grid((c->W + 7) / 8, (c->H + bh - 1) / bh);
         const int fixed = G == 4 ? kCoopFixedFloats<4> : kCoopFixedFloats<8>;
-        const size_t lds = (size_t)(fixed + (use_ref_tile(scale) ? (8 + 2 * radius) * (bh + 2 * radius) : 0)) * sizeof(float);
+        const size_t lds = (size_t)(fixed + (use_ref_tile(scale, 8, bh) ? (8 + 2 * radius) * (bh + 2 * radius) : 0)) * sizeof(float);
 #define PM_LAUNCH_COOP(U8, G_, WV) \
     hipLaunchKernelGGL((k_eval_ncc_coop<U8, G_, WV>), grid, dim3(256), lds, c->stream, c->dP, d_pl.as<float4>(), nh, d_out.as<float>(), a)
         if (c->all_u8) {

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256, WAVES) void k_eval_ncc_coop(const ProblemDev* 
     stage_views(P, vl, U8);
     int tpitch;
     const float* ctr = ref_center(P, tile, x, y, x0, y0, BW, BH, radius, a.scale, tpitch);
-    if (!use_ref_tile(a.scale)) __syncthreads();  // the staged view table
+    if (!use_ref_tile(a.scale, BW, BH)) __syncthreads();  // the staged view table
     if (!valid) return;
     const int idx = y * P.W + x;
     RefWin rw;

@@ -483,7 +483,11 @@ struct BilinearTap<false> {
         ax = __builtin_amdgcn_fractf(cx);  // v_fract_f32: x - floor(x), kept below 1
         ay = __builtin_amdgcn_fractf(cy);
         const int off = tex_byte_offset<4>(t, floor_to_int(cy), floor_to_int(cx));
+#ifdef PM_DBG_NOLOAD  // measurement builds only (results are wrong): the instruction stream without its gathers
+        q = (f32x4q){(float)off, 1.0f, ax, ay};
+#else
         q = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(t.rsrc, off, 0, 0));
+#endif
     }
     PM_DEV float value() const {
         const float top = __builtin_fmaf(ax, q.y, q.x);
@@ -714,12 +718,20 @@ PM_DEV void project(const CamDev& cam, float p0, float p1, float p2, float& u, f
     u = ((cam.K[0] * t0 + cam.K[1] * t1) + cam.K[2] * t2) / d;
     v = ((cam.K[3] * t0 + cam.K[4] * t1) + cam.K[5] * t2) / d;
 }
-PM_DEV float geom_cost(const ProblemDev& P, const ViewDev& vw, const float4 pl, int px, int py) {
-    const float depth = depth_from_plane(P, pl, px, py);
+// ComputeGeomConsistencyCost (ref .cu:617-640) in two halves: the world point of pixel (px, py) on the hypothesis plane does
+// not depend on the source view (ref :621-624 recomputes it per view: 3 of the 9 divisions of a check), the reprojection does.
+struct GeomPoint {
     float w0, w1, w2;
-    backproject(P.cam, (float)px, (float)py, depth, w0, w1, w2);
+};
+PM_DEV GeomPoint geom_world_point(const ProblemDev& P, const float4 pl, int px, int py) {
+    const float depth = depth_from_plane(P, pl, px, py);
+    GeomPoint g;
+    backproject(P.cam, (float)px, (float)py, depth, g.w0, g.w1, g.w2);
+    return g;
+}
+PM_DEV float geom_cost_view_body(const ProblemDev& P, const ViewDev& vw, const GeomPoint g, int px, int py) {
     float su, sv;
-    project(vw.cam, w0, w1, w2, su, sv);
+    project(vw.cam, g.w0, g.w1, g.w2, su, sv);
     float qx = (su >= 0.0f) ? su : 0.0f;
     qx = (qx <= vw.dwm1) ? qx : vw.dwm1;
     float qy = (sv >= 0.0f) ? sv : 0.0f;
@@ -733,6 +745,22 @@ PM_DEV float geom_cost(const ProblemDev& P, const ViewDev& vw, const float4 pl, 
     const float dc = (float)px - bu, dr = (float)py - bv;
     const float e = __builtin_sqrtf(dc * dc + dr * dr);
     return (e < 3.0f) ? e : 3.0f;
+}
+// CALL = true: a real function call instead of inlining.  The update kernel inlines the check three times next to the
+// unrolled NCC loop; with more than 8 views (bigger per-view arrays) that pushed the geometric variants into hundreds of
+// spilled registers (0.100 instead of 0.048 ns per evaluation at 20 views); at 8 views inlining is the faster form.
+__device__ __attribute__((noinline)) float geom_cost_view_call(const ProblemDev& P, const ViewDev& vw, const GeomPoint g, int px, int py) {
+    return geom_cost_view_body(P, vw, g, px, py);
+}
+template <bool CALL>
+PM_DEV float geom_cost_view(const ProblemDev& P, const ViewDev& vw, const GeomPoint g, int px, int py) {
+    if constexpr (CALL)
+        return geom_cost_view_call(P, vw, g, px, py);
+    else
+        return geom_cost_view_body(P, vw, g, px, py);
+}
+PM_DEV float geom_cost(const ProblemDev& P, const ViewDev& vw, const float4 pl, int px, int py) {
+    return geom_cost_view_body(P, vw, geom_world_point(P, pl, px, py), px, py);
 }
 
 }  // namespace pm

@@ -112,19 +112,23 @@ PM_DEV bool dense_pixel(const ProblemDev& P, int& x, int& y) {
 // dynamic LDS of the NCC kernels: 18 float4 weight records per thread + the reference tile
 extern __shared__ float pm_lds[];
 constexpr int kLdsWeightFloats = 2 * 36 * kBlockThreads;
-// The reference tile is staged in LDS only while two blocks still fit a CU's 160 KB
-// (scales 0 and 1: 4.4 / 7.5 KB).  At scale 2 (16 KB) it would halve the occupancy
-// of the whole kernel for the sake of the prologue (measured 5.96 vs 3.9 ms per
-// launch), so the window is read from the L2-resident padded image instead.
-__host__ __device__ inline bool use_ref_tile(int scale) { return scale < 2; }
+// The reference tile (block + halo of the window radius) is staged in LDS only while two blocks still fit a CU's 160 KB
+// next to their 72 KB of weight records, i.e. up to 2048 floats.  A larger tile would halve the occupancy of the whole
+// kernel for the sake of its prologue (measured 5.96 vs 3.9 ms per launch at scale 2), so the window is then read from the
+// L2-resident padded image instead.  With the 8 x 64 pixel blocks of the fp16 texture format that is the case from scale 1
+// on (28 x 84 floats), with the 16 x 32 blocks of the fp32 format and the 16 x 16 dense blocks from scale 2 on.
+__host__ __device__ inline bool use_ref_tile(int scale, int bw, int bh) {
+    const int radius = 5 * (2 << scale) / 2;
+    return (bw + 2 * radius) * (bh + 2 * radius) <= 2048;
+}
 inline size_t ncc_lds_bytes(int bw, int bh, int scale) {
     const int radius = 5 * (2 << scale) / 2;
-    const int tile = use_ref_tile(scale) ? (bw + 2 * radius) * (bh + 2 * radius) : 0;
+    const int tile = use_ref_tile(scale, bw, bh) ? (bw + 2 * radius) * (bh + 2 * radius) : 0;
     return (size_t)(kLdsWeightFloats + tile) * sizeof(float);
 }
 // pointer to pixel (x, y) with all its window taps addressable, and its pitch
 PM_DEV const float* ref_center(const ProblemDev& P, float* tile, int x, int y, int x0, int y0, int bw, int bh, int radius, int scale, int& pitch) {
-    if (use_ref_tile(scale)) {
+    if (use_ref_tile(scale, bw, bh)) {
         load_ref_tile(P, tile, x0, y0, bw, bh, radius);
         __syncthreads();
         pitch = bw + 2 * radius;
@@ -207,9 +211,20 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_init(const ProblemDe
     S.sel[idx] = sel;
 }
 
-PM_DEV float prior_term(float depth_diff, float angle_cos, float two_ds2, float two_as2) {
+PM_DEV float prior_term_body(float depth_diff, float angle_cos, float two_ds2, float two_as2) {
     const float ad = d_acos(angle_cos);
     return 0.5f + d_exp(-depth_diff * depth_diff / two_ds2) * d_exp(-ad * ad / two_as2);
+}
+// as a real call for the many-view variants of the update kernel (register pressure, see geom_cost_view)
+__device__ __attribute__((noinline)) float prior_term_call(float depth_diff, float angle_cos, float two_ds2, float two_as2) {
+    return prior_term_body(depth_diff, angle_cos, two_ds2, two_as2);
+}
+template <bool CALL>
+PM_DEV float prior_term(float depth_diff, float angle_cos, float two_ds2, float two_as2) {
+    if constexpr (CALL)
+        return prior_term_call(depth_diff, angle_cos, two_ds2, two_as2);
+    else
+        return prior_term_body(depth_diff, angle_cos, two_ds2, two_as2);
 }
 
 // ---------------------------------------------------------------------------
@@ -219,6 +234,7 @@ PM_DEV float prior_term(float depth_diff, float angle_cos, float two_ds2, float 
 template <bool GEOM, bool PRIOR, int MAXV, bool U8>
 __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
     const ProblemDev& P = *Pp;
+    constexpr bool kGeomCall = MAXV > 8;  // see geom_cost_view
     int x, y, x0, y0;
     const bool valid = checker_pixel<U8>(P, a, x, y, x0, y0);
     const int step = 2 << a.scale, radius = 5 * step / 2;
@@ -283,85 +299,109 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
     int min_idx = 0;
     bool masked = false;
 
-    for (int slot = 0; slot < 14; ++slot) {
+    // ---- phase A: the 8 propagated candidates against every view (ref .cu:798-819).  Two loops over ONE kind of work each
+    // (instead of one loop over 14 slots) keep the state of the later phases -- accepted plane, refinement candidates, prior --
+    // out of the registers while the candidates are evaluated, and the other way round.
+    for (int slot = 0; slot < 8; ++slot) {
+        const bool active = (flags >> slot) & 1u;
+        const float4 pl = active ? S.planes[pos[slot]] : make_float4(0.f, 0.f, 0.f, 1.f);
+        float m0, m1, m2;
+        plane_to_m(P, pl, m0, m1, m2);
+        for (int v = 0; v < V; ++v) {
+            float c;
+            if (active)
+                c = ncc_cost<U8>(P.views[v], rw, x, y, step, radius, m0, m1, m2);
+            else
+                c = (slot == 0 && v == 0) ? 2.0f : 0.0f;  // `= {2.0f}` initialiser quirk, ref .cu:795
+            cost_arr[slot * MAXV + v] = c;
+            if (c < thr) {
+                tmpw[v] += d_exp_inrange((c * c) / (-0.18f));  // c in [0, 2]: argument in [-22.3, 0]
+                cnt[v] += 1;
+            }
+            if (c > 1.2f) cnt[v] += 256;
+        }
+    }
+    {
+    // ---- view weights (ref .cu:821-878)
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (flags & 1u) s0 = S.sel[idx - W];
+    if (flags & 2u) s1 = S.sel[idx + W];
+    if (flags & 4u) s2 = S.sel[idx - 1];
+    if (flags & 8u) s3 = S.sel[idx + 1];
+    float psum = 0.0f;
+    for (int v = 0; v < V; ++v) {
+        float vp = 0.0f;
+        if (flags & 1u) vp += ((s0 >> v) & 1u) ? 0.9f : 0.1f;
+        if (flags & 2u) vp += ((s1 >> v) & 1u) ? 0.9f : 0.1f;
+        if (flags & 4u) vp += ((s2 >> v) & 1u) ? 0.9f : 0.1f;
+        if (flags & 8u) vp += ((s3 >> v) & 1u) ? 0.9f : 0.1f;
+        const int good = cnt[v] & 0xff, bad = cnt[v] >> 8;
+        float pr;
+        if (good > 2 && bad < 3)
+            pr = (vp * tmpw[v]) / (float)good;
+        else if (bad < 3)
+            pr = vp * d_exp((thr * thr) / (-0.32f));
+        else
+            pr = 0.0f;
+        probs[v] = pr;
+        psum += pr;
+    }
+    const float inv = 1.0f / psum;  // 0 * inf = NaN when everything vanished (ref .cu:42-56)
+    float cum = 0.0f;
+    for (int v = 0; v < V; ++v) {
+        cum += probs[v] * inv;
+        probs[v] = cum;
+    }
+    probs[V - 1] = 1.0f;
+    for (int s = 0; s < 15; ++s) {
+        const float rp = rng_uniform(g) - 1.1920928955078125e-7f;
+        for (int v = 0; v < V; ++v)
+            if (probs[v] > rp) {
+                view_w[v] += 1.0f;
+                break;
+            }
+    }
+    for (int v = 0; v < V; ++v)
+        if (view_w[v] > 0.0f) {
+            temp_sel |= (1u << v);
+            weight_norm += view_w[v];
+        }
+    // ---- weighted candidate costs (ref .cu:880-899)
+    for (int i = 0; i < 8; ++i) {
+        const bool fl = (flags >> i) & 1u;
+        GeomPoint gp{0.f, 0.f, 0.f};
+        if (GEOM && fl) gp = geom_world_point(P, S.planes[pos[i]], x, y);
+        float fc = 0.0f;
+        for (int v = 0; v < V; ++v) {
+            if (view_w[v] > 0.0f) {
+                if (GEOM) {
+                    if (fl)
+                        fc += view_w[v] * (cost_arr[i * MAXV + v] + 0.2f * geom_cost_view<kGeomCall>(P, P.views[v], gp, x, y));
+                    else
+                        fc += view_w[v] * (cost_arr[i * MAXV + v] + 0.1f * 3.0f);
+                } else {
+                    fc += view_w[v] * cost_arr[i * MAXV + v];
+                }
+            }
+        }
+        final_costs[i] = fc / weight_norm;
+    }
+    {
+        float mc = final_costs[0];
+        for (int i = 1; i < 8; ++i)
+            if (final_costs[i] <= mc) {
+                mc = final_costs[i];
+                min_idx = i;
+            }
+    }
+    }
+
+    // ---- phase B: the current plane under the new weights (slot 8), then the 5 refinement candidates (slots 9..13).  From
+    // here on a view with weight 0 contributes exactly +0.0 to every sum (all costs are finite), so its evaluation is dead
+    // work; the reference computes it regardless (ref .cu:681,903).
+    for (int slot = 8; slot < 14; ++slot) {
         float4 pl;
-        bool active = true;
-        if (slot < 8) {
-            active = (flags >> slot) & 1u;
-            pl = active ? S.planes[pos[slot]] : make_float4(0.f, 0.f, 0.f, 1.f);
-        } else if (slot == 8) {
-            // ---- view weights (ref .cu:821-878)
-            uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-            if (flags & 1u) s0 = S.sel[idx - W];
-            if (flags & 2u) s1 = S.sel[idx + W];
-            if (flags & 4u) s2 = S.sel[idx - 1];
-            if (flags & 8u) s3 = S.sel[idx + 1];
-            float psum = 0.0f;
-            for (int v = 0; v < V; ++v) {
-                float vp = 0.0f;
-                if (flags & 1u) vp += ((s0 >> v) & 1u) ? 0.9f : 0.1f;
-                if (flags & 2u) vp += ((s1 >> v) & 1u) ? 0.9f : 0.1f;
-                if (flags & 4u) vp += ((s2 >> v) & 1u) ? 0.9f : 0.1f;
-                if (flags & 8u) vp += ((s3 >> v) & 1u) ? 0.9f : 0.1f;
-                const int good = cnt[v] & 0xff, bad = cnt[v] >> 8;
-                float pr;
-                if (good > 2 && bad < 3)
-                    pr = (vp * tmpw[v]) / (float)good;
-                else if (bad < 3)
-                    pr = vp * d_exp((thr * thr) / (-0.32f));
-                else
-                    pr = 0.0f;
-                probs[v] = pr;
-                psum += pr;
-            }
-            const float inv = 1.0f / psum;  // 0 * inf = NaN when everything vanished (ref .cu:42-56)
-            float cum = 0.0f;
-            for (int v = 0; v < V; ++v) {
-                cum += probs[v] * inv;
-                probs[v] = cum;
-            }
-            probs[V - 1] = 1.0f;
-            for (int s = 0; s < 15; ++s) {
-                const float rp = rng_uniform(g) - 1.1920928955078125e-7f;
-                for (int v = 0; v < V; ++v)
-                    if (probs[v] > rp) {
-                        view_w[v] += 1.0f;
-                        break;
-                    }
-            }
-            for (int v = 0; v < V; ++v)
-                if (view_w[v] > 0.0f) {
-                    temp_sel |= (1u << v);
-                    weight_norm += view_w[v];
-                }
-            // ---- weighted candidate costs (ref .cu:880-899)
-            for (int i = 0; i < 8; ++i) {
-                const bool fl = (flags >> i) & 1u;
-                float4 cpl = make_float4(0.f, 0.f, 0.f, 1.f);
-                if (GEOM && fl) cpl = S.planes[pos[i]];
-                float fc = 0.0f;
-                for (int v = 0; v < V; ++v) {
-                    if (view_w[v] > 0.0f) {
-                        if (GEOM) {
-                            if (fl)
-                                fc += view_w[v] * (cost_arr[i * MAXV + v] + 0.2f * geom_cost(P, P.views[v], cpl, x, y));
-                            else
-                                fc += view_w[v] * (cost_arr[i * MAXV + v] + 0.1f * 3.0f);
-                        } else {
-                            fc += view_w[v] * cost_arr[i * MAXV + v];
-                        }
-                    }
-                }
-                final_costs[i] = fc / weight_norm;
-            }
-            {
-                float mc = final_costs[0];
-                for (int i = 1; i < 8; ++i)
-                    if (final_costs[i] <= mc) {
-                        mc = final_costs[i];
-                        min_idx = i;
-                    }
-            }
+        if (slot == 8) {
             pl = cur;
         } else {
             if (slot == 9) {
@@ -379,7 +419,7 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
                                 const float4 cpl = S.planes[pos[i]];
                                 const float di = depth_from_plane(P, cpl, x, y);
                                 const float ac = (pp.x * cpl.x + pp.y * cpl.y) + pp.z * cpl.z;
-                                const float pr = prior_term(di - depth_prior, ac, two_ds2, two_as2);
+                                const float pr = prior_term<kGeomCall>(di - depth_prior, ac, two_ds2, two_as2);
                                 rfc[i] = d_exp(-final_costs[i] * final_costs[i] / beta) * pr;
                             }
                         }
@@ -391,7 +431,7 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
                                 max_idx = i;
                             }
                         const float ac = (pp.x * cur.x + pp.y * cur.y) + pp.z * cur.z;
-                        const float pr = prior_term(depth_now - depth_prior, ac, two_ds2, two_as2);
+                        const float pr = prior_term<kGeomCall>(depth_now - depth_prior, ac, two_ds2, two_as2);
                         const float rc_now = d_exp(-cost_now * cost_now / beta) * pr;
                         if ((flags >> max_idx) & 1u) {
                             const float4 cpl = S.planes[pos[max_idx]];
@@ -446,40 +486,18 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
 
         float m0, m1, m2;
         plane_to_m(P, pl, m0, m1, m2);
+        GeomPoint gp{0.f, 0.f, 0.f};
+        if (GEOM) gp = geom_world_point(P, pl, x, y);
         float tc = 0.0f, tg = 0.0f;
         for (int v = 0; v < V; ++v) {
-            // From slot 8 on a view with weight 0 contributes exactly +0.0 to
-            // every sum below (all costs are finite), so its evaluation is dead
-            // work; the reference computes it regardless (ref .cu:681,903).
-            if (slot >= 8 && !(view_w[v] > 0.0f)) continue;
-            float c;
-            if (active)
-                c = ncc_cost<U8>(P.views[v], rw, x, y, step, radius, m0, m1, m2);
-            else
-                c = (slot == 0 && v == 0) ? 2.0f : 0.0f;  // `= {2.0f}` initialiser quirk, ref .cu:795
-            if (slot < 8) {
-                cost_arr[slot * MAXV + v] = c;
-                if (c < thr) {
-                    tmpw[v] += d_exp_inrange((c * c) / (-0.18f));  // c in [0, 2]: argument in [-22.3, 0]
-                    cnt[v] += 1;
-                }
-                if (c > 1.2f) cnt[v] += 256;
-            } else if (slot == 8) {
-                if (GEOM) {
-                    const float gt = 0.2f * geom_cost(P, P.views[v], pl, x, y);
-                    tc += view_w[v] * (c + gt);
-                    tg += view_w[v] * gt;
-                } else {
-                    tc += view_w[v] * c;
-                }
-            } else if (view_w[v] > 0.0f) {
-                if (GEOM) {
-                    const float gt = 0.2f * geom_cost(P, P.views[v], pl, x, y);
-                    tc += view_w[v] * (c + gt);
-                    tg += view_w[slot - 9] * gt;  // candidate index used as view index, ref .cu:689
-                } else {
-                    tc += view_w[v] * c;
-                }
+            if (!(view_w[v] > 0.0f)) continue;
+            const float c = ncc_cost<U8>(P.views[v], rw, x, y, step, radius, m0, m1, m2);
+            if (GEOM) {
+                const float gt = 0.2f * geom_cost_view<kGeomCall>(P, P.views[v], gp, x, y);
+                tc += view_w[v] * (c + gt);
+                tg += (slot == 8 ? view_w[v] : view_w[slot - 9]) * gt;  // refinement: candidate index used as view index, ref .cu:689
+            } else {
+                tc += view_w[v] * c;
             }
         }
         if (slot == 8) {
@@ -491,7 +509,7 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
             const float db = depth_from_plane(P, pl, x, y);
             if (masked) {
                 const float ac = (pp.x * pl.x + pp.y * pl.y) + pp.z * pl.z;
-                const float pr = prior_term(cand_depth - depth_prior, ac, two_ds2, two_as2);
+                const float pr = prior_term<kGeomCall>(cand_depth - depth_prior, ac, two_ds2, two_as2);
                 const float rtc = d_exp(-tc * tc / beta) * pr;
                 if (db >= a.depth_min && db <= a.depth_max && rtc > restricted_cost) {
                     plane_now = pl;

@@ -18,7 +18,7 @@ def test_random_configuration_bit_exact(pm, oracle, engine, case):
     rng = np.random.default_rng(1000 + case)
     W = int(rng.integers(6, 90))
     H = int(rng.integers(6, 70))
-    V = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12]))
+    V = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 20, 24, 25, 32]))   # every bucket of the update kernel (8 / 16 / 24 / 32 views) and its edges
     quantize = bool(rng.integers(0, 2))
     max_scale = int(rng.integers(0, 3))
     iters = int(rng.integers(1, 4))
@@ -69,3 +69,37 @@ def test_random_configuration_bit_exact(pm, oracle, engine, case):
             h.set_prior(prior, mask)
             h.run(p, 79 + case)
         assert _same(gpu.get()[0], cpu.get()[0]) and _same(gpu.get()[1], cpu.get()[1]), f"prior W={W} H={H} V={V}"
+
+
+@pytest.mark.parametrize("V", [9, 13, 16, 17, 20, 24])
+@pytest.mark.parametrize("quantize", [True, False])
+def test_many_views_all_modes_bit_exact(pm, oracle, engine, V, quantize):
+    """the shipped configuration allows 20 source views (reference config/config.yaml:19): photometric, geometric and
+    planar-prior Run() at 9..24 views, both texture formats, against the oracle"""
+    rng = np.random.default_rng(5000 + V)
+    W, H = 57, 41
+    sc = pm.synth.make_problem_scene(W, H, n_src=8, spacing=0.4, rot_deg=3.0, quantize=quantize, seed=V)
+    ids = [1 + (i % 8) for i in range(V)]
+    cams, imgs = sc.problem(0, ids)
+    dmin, dmax = pm.synth.kernel_depth_range(cams[0])
+    p = pm.PatchMatchParams(num_images=V + 1, depth_min=float(dmin), depth_max=float(dmax), max_scale=1, max_iterations=2)
+    gpu, cpu = engine.create(0), oracle.create()
+    for h in (gpu, cpu):
+        h.set_views(cams, imgs)
+        h.run(p, V)
+    assert _same(gpu.get()[0], cpu.get()[0]) and _same(gpu.get()[1], cpu.get()[1])
+    depths = [sc.views[i].gt_depth * (1.0 + 0.01 * rng.standard_normal((H, W))).astype(np.float32) for i in ids]
+    p.geom_consistency, p.max_iterations = True, 2
+    for h in (gpu, cpu):
+        h.set_src_depths(depths)
+        h.run(p, V + 1)
+    assert all(_same(a, b) for a, b in zip(gpu.get(geom=True), cpu.get(geom=True)))
+    prior = np.zeros((H, W, 4), np.float32)
+    prior[..., 2] = -1.0
+    prior[..., 3] = sc.views[0].gt_depth
+    mask = (rng.uniform(size=(H, W)) < 0.5).astype(np.uint32)
+    p.geom_consistency, p.planar_prior, p.max_iterations = False, True, 2
+    for h in (gpu, cpu):
+        h.set_prior(prior, mask)
+        h.run(p, V + 2)
+    assert _same(gpu.get()[0], cpu.get()[0]) and _same(gpu.get()[1], cpu.get()[1])

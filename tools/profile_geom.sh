@@ -3,7 +3,7 @@
 set -o pipefail
 OUT=$PWD/gpurun_out/prof_geom
 mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:?}
 python3 tools/bench_scales.py > $OUT/plain.json 2>/dev/null
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $OUT/pmc -- python3 tools/bench_scales.py > /dev/null 2> $OUT/pmc.err
 python3 - <<'PY'

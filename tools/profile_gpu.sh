@@ -3,14 +3,14 @@
 # usage: tools/profile_gpu.sh <tag>      -> gpurun_out/prof_<tag>/
 set -o pipefail
 TAG=${1:-r1}
-OUT=$PWD/gpurun_out/prof_$TAG
+export OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_plain.json 2>/dev/null   # also fills the scene cache
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_traced.json 2> $OUT/trace.err
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:?}
+python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary > $OUT/bench_plain.json 2>/dev/null   # also fills the scene cache
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/bench_traced.json 2> $OUT/trace.err
 pass() { # name, counters...
   n=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_$n -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$n.err || echo "pmc pass $n failed" >> $OUT/errors.txt
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_$n -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary > /dev/null 2> $OUT/pmc_$n.err || echo "pmc pass $n failed" >> $OUT/errors.txt
 }
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
 pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_INSTS_LDS SQ_WAIT_INST_LDS

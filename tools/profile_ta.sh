@@ -2,13 +2,13 @@
 # Texture-addresser / L1 (TA, TCP, TD) utilisation of the update kernel: is the gather path, not the VALU, the limiter?
 # Run on the GPU box via gpurun; each counter group in its own rocprofv3 pass.
 set -o pipefail
-OUT=$PWD/gpurun_out/prof_ta
+export OUT=$PWD/gpurun_out/prof_ta
 mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:?}
+python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary > /dev/null 2>&1
 # at most 2 counters of one hardware block per pass ("Request exceeds the capabilities of the hardware" otherwise, after
 # which rocprofv3 aborts and hangs); every pass bounded by timeout and announced, so a stuck pass cannot look like a hung run
-pass() { n=$1; shift; echo "pass $n: $*"; timeout -k 10 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$n -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $OUT/$n.err || echo "pass $n failed"; }
+pass() { n=$1; shift; echo "pass $n: $*"; timeout -k 10 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$n -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary > /dev/null 2> $OUT/$n.err || echo "pass $n failed"; }
 pass ta_a TA_TA_BUSY TA_BUFFER_WAVEFRONTS GRBM_GUI_ACTIVE
 pass ta_b TA_BUFFER_TOTAL_CYCLES TA_ADDR_STALLED_BY_TC_CYCLES
 pass ta_c TA_ADDR_STALLED_BY_TD_CYCLES TA_DATA_STALLED_BY_TC_CYCLES
