@@ -477,6 +477,7 @@ inline float ncc_cost(const Ctx& c, const RefWin& rw, int px, int py, const floa
         if (!(cx >= 0.0f && cx < vc.wf && cy >= 0.0f && cy < vc.hf)) return 2.0f;  // ref .cu:351-353
     }
     float T1 = 0.0f, T2 = 0.0f, T3 = 0.0f;
+    float racc = 0.0f;
     for (int a = 0; a < 6; ++a) {
         const float tx = (float)(px + rw.dx[a]);
         const float Cx = fmaf(Hm[0], tx, Hm[2]);
@@ -494,7 +495,10 @@ inline float ncc_cost(const Ctx& c, const RefWin& rw, int px, int py, const floa
         {
             const float q0 = Z[0] * Z[1], q1 = Z[2] * Z[3], q2 = Z[4] * Z[5];
             const float t = q0 * q1, u = q1 * q2, v = q0 * q2;
+            // det_rcp maps an infinite / NaN product to -+inf / NaN and a zero / denormal one to +-inf: the sum of the six
+            // column reciprocals is finite exactly when every column had a usable one (checked after the loop)
             const float r = det_rcp(t * q2);
+            racc += r;
             const float iq0 = r * u, iq1 = r * v, iq2 = r * t;
             I[0] = iq0 * Z[1];
             I[1] = iq0 * Z[0];
@@ -524,6 +528,8 @@ inline float ncc_cost(const Ctx& c, const RefWin& rw, int px, int py, const floa
         T2 += E2 + O2;
         T3 += E3 + O3;
     }
+    // near-degenerate planes (the reference divides per tap and gets garbage coordinates there): sentinel cost
+    if (!std::isfinite(racc)) return 2.0f;
     const float ms = T1 * rw.inv_w, mss = T2 * rw.inv_w, mrs = T3 * rw.inv_w;
     const float var_s = fmaf(-ms, ms, mss);
     if (rw.var_r < 1e-5f || var_s < 1e-5f) return 2.0f;  // ref .cu:406-408

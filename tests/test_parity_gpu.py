@@ -519,3 +519,24 @@ def test_near_black_images_bit_exact(pm, oracle, engine):
     for h in (gpu, cpu):
         h.run(p, 9)
     assert all(np.array_equal(a, b) for a, b in zip(gpu.get(), cpu.get()))
+
+
+def test_degenerate_planes_take_the_sentinel_cost(pm, oracle, engine):
+    """planes that (almost) contain the camera centre: the product of the six depths of a window column leaves the range of
+    the shared reciprocal.  Such evaluations are the sentinel cost 2 on both sides, never a value computed
+    from a collapsed warp."""
+    W, H, V = 64, 48, 3
+    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, W, H, V, quantize=True)
+    rng = np.random.default_rng(42)
+    planes = random_planes(pm, sc.views[0].cam, W, H, rng, prm.depth_min, prm.depth_max)
+    planes[::2, :, 3] *= np.float32(1e-9)                      # plane offset ~ 0: homography entries ~ 1e9
+    planes[1::4, :, 3] = np.float32(0.0)                        # exactly through the camera centre: 1 / d = inf
+    planes[:, ::5, 3] *= rng.choice([1e-7, 1e-8, 1e8, -1e-9], size=(H, len(range(0, W, 5)))).astype(np.float32)
+    for scale in (0, 2):
+        got = gpu.eval_ncc(prm, planes, scale)
+        want = cpu.eval_ncc(prm, planes, scale)
+        assert_same(f"degenerate planes, scale {scale}", got, want)
+        tiny = np.zeros((H, W), bool)
+        tiny[::2] = True
+        assert (want[:, tiny] == 2.0).mean() > 0.99             # nothing but the sentinel where the warp is meaningless
+        assert (want[:, ~tiny] < 2.0).mean() > 0.2              # and ordinary costs elsewhere
