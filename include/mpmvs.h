@@ -190,6 +190,11 @@ int mpmvs_rng(uint64_t seed, uint32_t pix, uint32_t launch_id, int n, void* out)
  * Outputs per image: out_valid (1 where a fused point was produced), out_points9
  * (x y z nx ny nz c0 c1 c2 per pixel, colour in the input channel order), out_masks
  * (pixels consumed by points of other images, and sky pixels).  Host buffers in and out. */
+/* use_dynamic_consistency is a set of flags: */
+#define MPMVS_FUSE_DYNAMIC_CONSISTENCY 1 /* config `use_dynamic_consistency` (src/PatchMatch.cpp:458) */
+#define MPMVS_FUSE_REFERENCE_ORDER 2     /* the reference's sequential masking order (in-place masks, persistent used_list,
+                                            src/PatchMatch.cpp:382,416,470-495) instead of the snapshot formulation: same result as
+                                            the sequential loop, computed as a parallel fixpoint */
 int mpmvs_fuse(int device, int n, const mpmvs_camera* cams, const int* estimate, const float* const* depths,
                const float* const* normals, const unsigned char* const* colors, int color_channels,
                const unsigned char* const* sky, const int* src_off, const int* src_ids, int use_dynamic_consistency,
@@ -208,6 +213,8 @@ void mpmvs_free(void* p);
 
 /* device time (ms, HIP events) of the kernels of the last mpmvs_fuse / mpmvs_fuse_ply call */
 float mpmvs_fuse_kernel_ms(void);
+/* fixpoint passes of the last MPMVS_FUSE_REFERENCE_ORDER call: sum over the images and the largest count of one image */
+void mpmvs_fuse_passes(int* total, int* max_per_image);
 
 /* ---- sky-mask refinement --------------------------------------- */
 /* The device half of bilateral_filter (SkySegment/src/SkyRegionDetect.cu:36-66: the

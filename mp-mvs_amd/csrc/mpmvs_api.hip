@@ -1050,15 +1050,24 @@ int mpmvs_rng(uint64_t seed, uint32_t pix, uint32_t launch_id, int n, void* out)
 }
 
 static float g_fuse_kernel_ms = 0.0f;
+static int g_fuse_passes_total = 0, g_fuse_passes_max = 0;
 // device time of the kernels (and mask copies) of the last mpmvs_fuse call, HIP events
 float mpmvs_fuse_kernel_ms(void) { return g_fuse_kernel_ms; }
+// passes of the last MPMVS_FUSE_REFERENCE_ORDER call: *total over all images, *max for one image (either may be NULL)
+void mpmvs_fuse_passes(int* total, int* max_per_image) {
+    if (total) *total = g_fuse_passes_total;
+    if (max_per_image) *max_per_image = g_fuse_passes_max;
+}
 
 // depth-map fusion, snapshot formulation (pm_fusion.hpp); host buffers in and out.  With `records` the fused points are
 // compacted on the device into PLY vertex records (reference PointCloud order) and only those cross PCIe.
 static int fuse_impl(int device, int n, const mpmvs_camera* cams, const int* estimate, const float* const* depths, const float* const* normals,
                      const unsigned char* const* colors, int color_channels, const unsigned char* const* sky, const int* src_off, const int* src_ids,
-                     int use_dynamic, unsigned char* const* out_valid, float* const* out_points9, unsigned char* const* out_masks,
+                     int flags, unsigned char* const* out_valid, float* const* out_points9, unsigned char* const* out_masks,
                      unsigned char** records, long long* n_records) {
+    const int use_dynamic = flags & MPMVS_FUSE_DYNAMIC_CONSISTENCY;
+    const bool exact = (flags & MPMVS_FUSE_REFERENCE_ORDER) != 0;
+    g_fuse_passes_total = g_fuse_passes_max = 0;
     if (n <= 0 || (color_channels != 1 && color_channels != 3) || enter_device(device) != hipSuccess) return -1;
     // every view id is used as an index below (host vectors, FuseView table, masks): reject lists that name images that do
     // not exist before anything is launched (the reference looks ids up in a map, src/PatchMatch.cpp:306-312)
@@ -1083,7 +1092,18 @@ static int fuse_impl(int device, int n, const mpmvs_camera* cams, const int* est
     std::vector<unsigned char*> d_valid(n, nullptr);
     std::vector<float*> d_out(n, nullptr);
     std::vector<unsigned char*> d_mask(n, nullptr), d_next(n, nullptr);
-    size_t total_px = 0, max_blocks = 0;
+    size_t total_px = 0, max_blocks = 0, max_wh = 0;
+    int max_ngb = 1;
+    for (int i = 0; i < n; ++i)
+        if (estimate[i]) {
+            max_wh = std::max(max_wh, (size_t)cams[i].width * cams[i].height);
+            max_ngb = std::max(max_ngb, src_off[i + 1] - src_off[i]);
+        }
+    // with `records` the per-pixel outputs of an image are consumed (compacted) before the next image is fused: one buffer
+    // of the largest size serves all images (the per-image form would be 37 B per pixel of the whole dataset)
+    unsigned char* shared_valid = records ? (unsigned char*)dalloc(max_wh) : nullptr;
+    float* shared_out = records ? (float*)dalloc(max_wh * 36) : nullptr;
+    if (records && (!shared_valid || !shared_out)) rc = -100;
     for (int i = 0; i < n && !rc; ++i) {
         const size_t wh = (size_t)cams[i].width * cams[i].height;
         if (estimate[i]) {
@@ -1100,13 +1120,19 @@ static int fuse_impl(int device, int n, const mpmvs_camera* cams, const int* est
         unsigned char* dsky = (sky && sky[i]) ? (unsigned char*)dalloc(wh) : nullptr;
         d_mask[i] = (unsigned char*)dalloc(wh);
         d_next[i] = (unsigned char*)dalloc(wh);
-        d_valid[i] = (unsigned char*)dalloc(wh);
-        d_out[i] = (float*)dalloc(wh * 36);
+        d_valid[i] = records ? shared_valid : (unsigned char*)dalloc(wh);
+        d_out[i] = records ? shared_out : (float*)dalloc(wh * 36);
+        int* dtau = exact ? (int*)dalloc(wh * 4) : nullptr;
+        int* dtau_new = exact ? (int*)dalloc(wh * 4) : nullptr;
+        if (exact && (!dtau || !dtau_new)) { rc = -100; break; }
+        v.tau = dtau;
+        v.tau_new = dtau_new;
         if (!dd || !dn || !dg || (sky && sky[i] && !dsky) || !d_mask[i] || !d_next[i] || !d_valid[i] || !d_out[i]) { rc = -100; break; }
         if (hipMemcpyAsync(dd, depths[i], wh * 4, hipMemcpyHostToDevice, st) != hipSuccess || hipMemcpyAsync(dn, normals[i], wh * 12, hipMemcpyHostToDevice, st) != hipSuccess ||
             hipMemcpyAsync(dg, colors[i], wh * color_channels, hipMemcpyHostToDevice, st) != hipSuccess || (dsky && hipMemcpyAsync(dsky, sky[i], wh, hipMemcpyHostToDevice, st) != hipSuccess) ||
             hipMemsetAsync(d_mask[i], 0, wh, st) != hipSuccess ||
-            hipMemsetAsync(d_next[i], 0, wh, st) != hipSuccess || hipMemsetAsync(d_valid[i], 0, wh, st) != hipSuccess || (!records && hipMemsetAsync(d_out[i], 0, wh * 36, st) != hipSuccess))
+            hipMemsetAsync(d_next[i], 0, wh, st) != hipSuccess || (!records && hipMemsetAsync(d_valid[i], 0, wh, st) != hipSuccess) ||
+            (!records && hipMemsetAsync(d_out[i], 0, wh * 36, st) != hipSuccess))
             rc = -100;
         v.depth = dd;
         v.normal = dn;
@@ -1134,6 +1160,17 @@ static int fuse_impl(int device, int n, const mpmvs_camera* cams, const int* est
         d_records = (unsigned char*)dalloc(total_px * kPlyRecord);  // upper bound: every pixel a point
         if (!d_blocks || !d_base || !d_records || hipMemsetAsync(d_base, 0, sizeof(long long), st) != hipSuccess) rc = -100;
     }
+    // exact mode scratch: per source slot the consistent source pixel of every pixel, the chunk carries of the scan, a counter
+    int* d_consq = nullptr;
+    int* d_carry = nullptr;
+    int* d_diff = nullptr;
+    const size_t max_chunks = (max_wh + 255) / 256;
+    if (!rc && exact) {
+        d_consq = (int*)dalloc((size_t)(max_ngb - 1 > 0 ? max_ngb - 1 : 1) * max_wh * 4);
+        d_carry = (int*)dalloc((size_t)(max_ngb - 1 > 0 ? max_ngb - 1 : 1) * max_chunks * 4);
+        d_diff = (int*)dalloc(4);
+        if (!d_consq || !d_carry || !d_diff) rc = -100;
+    }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     (void)hipEventCreate(&ev0);
     (void)hipEventCreate(&ev1);
@@ -1143,12 +1180,59 @@ static int fuse_impl(int device, int n, const mpmvs_camera* cams, const int* est
         const int b = src_off[i], num_ngb = src_off[i + 1] - b;
         if (num_ngb > kMaxFuseNgb) { rc = -2; break; }
         const dim3 grid((hv[i].w + 31) / 32, (hv[i].h + 7) / 8);
-        hipLaunchKernelGGL(k_fuse, grid, dim3(256), 0, st, d_views, i, d_src + b, num_ngb, use_dynamic, d_valid[i], d_out[i]);
-        if (hipGetLastError() != hipSuccess) { rc = -100; break; }
-        // the marks of image i become the masks the next image sees
-        for (int j = 1; j < num_ngb; ++j) {
-            const int s = src_ids[b + j];
-            if (hipMemcpyAsync(d_mask[s], d_next[s], (size_t)hv[s].w * hv[s].h, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = -100;
+        if (records && hipMemsetAsync(d_valid[i], 0, (size_t)hv[i].w * hv[i].h, st) != hipSuccess) { rc = -100; break; }
+        if (!exact) {
+            hipLaunchKernelGGL(k_fuse<false>, grid, dim3(256), 0, st, d_views, i, d_src + b, num_ngb, use_dynamic, d_valid[i], d_out[i], (int*)nullptr);
+            if (hipGetLastError() != hipSuccess) { rc = -100; break; }
+            // the marks of image i become the masks the next image sees
+            for (int j = 1; j < num_ngb; ++j) {
+                const int s = src_ids[b + j];
+                if (hipMemcpyAsync(d_mask[s], d_next[s], (size_t)hv[s].w * hv[s].h, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = -100;
+            }
+        } else {
+            // fixpoint over tau (pm_fusion.hpp): every pass re-evaluates all pixels of the image against the marking times of the
+            // previous pass; ends when the marking times repeat
+            const int npix = hv[i].w * hv[i].h, nchunks = (npix + 255) / 256;
+            for (int j = 1; j < num_ngb; ++j) {
+                const int s = src_ids[b + j], ns = hv[s].w * hv[s].h;
+                hipLaunchKernelGGL(k_fuse_tau_init, dim3((ns + 255) / 256), dim3(256), 0, st, d_mask[s], ns, hv[s].tau);
+            }
+            int passes = 0;
+            for (;;) {
+                ++passes;
+                for (int j = 1; j < num_ngb; ++j) {
+                    const int s = src_ids[b + j], ns = hv[s].w * hv[s].h;
+                    hipLaunchKernelGGL(k_fuse_tau_init, dim3((ns + 255) / 256), dim3(256), 0, st, d_mask[s], ns, hv[s].tau_new);
+                }
+                hipLaunchKernelGGL(k_fuse<true>, grid, dim3(256), 0, st, d_views, i, d_src + b, num_ngb, use_dynamic, d_valid[i], d_out[i], d_consq);
+                if (num_ngb > 1) {
+                    hipLaunchKernelGGL(k_fuse_carry_local, dim3(nchunks, num_ngb - 1), dim3(256), 0, st, d_consq, npix, nchunks, d_carry);
+                    hipLaunchKernelGGL(k_fuse_carry_chunks, dim3(num_ngb - 1), dim3(256), 0, st, d_carry, nchunks);
+                    hipLaunchKernelGGL(k_fuse_mark, dim3(nchunks), dim3(256), 0, st, d_views, d_src + b, num_ngb, d_valid[i], d_consq, d_carry, npix, nchunks);
+                }
+                if (hipMemsetAsync(d_diff, 0, 4, st) != hipSuccess) rc = -100;
+                for (int j = 1; j < num_ngb; ++j) {
+                    const int s = src_ids[b + j], ns = hv[s].w * hv[s].h;
+                    hipLaunchKernelGGL(k_fuse_tau_diff, dim3((ns + 255) / 256), dim3(256), 0, st, hv[s].tau, hv[s].tau_new, ns, d_diff);
+                }
+                int changed = 0;
+                if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&changed, d_diff, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess)
+                    rc = -100;
+                if (rc) break;
+                for (int j = 1; j < num_ngb; ++j) std::swap(hv[src_ids[b + j]].tau, hv[src_ids[b + j]].tau_new);
+                if (hipMemcpyAsync(d_views, hv.data(), sizeof(FuseView) * n, hipMemcpyHostToDevice, st) != hipSuccess) { rc = -100; break; }
+                if (changed == 0) break;   // tau (now in .tau) reproduces itself: the sequential result
+                if (passes > npix) { rc = -3; break; }   // cannot happen: every pass fixes at least one more pixel
+            }
+            g_fuse_passes_total += passes;
+            g_fuse_passes_max = std::max(g_fuse_passes_max, passes);
+            if (rc) break;
+            for (int j = 1; j < num_ngb; ++j) {
+                const int s = src_ids[b + j], ns = hv[s].w * hv[s].h;
+                hipLaunchKernelGGL(k_fuse_tau_to_mask, dim3((ns + 255) / 256), dim3(256), 0, st, hv[s].tau, ns, d_mask[s]);
+            }
+            if (hipGetLastError() != hipSuccess) { rc = -100; break; }
         }
         if (records && !rc) {
             const int wh = hv[i].w * hv[i].h, nb = (wh + 255) / 256;

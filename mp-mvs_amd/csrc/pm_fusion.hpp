@@ -9,6 +9,17 @@
 // they were when the image started; the masks it produces become visible to the next
 // image.  One thread = one pixel; HBM-bound (per pixel: own depth/normal/colour plus,
 // per source view, one mask byte, one depth, one normal, one colour).
+//
+// EXACT mode (k_fuse<true> + k_fuse_carry_* + k_fuse_mark) reproduces the reference's order-dependent result instead,
+// still in parallel, as a fixpoint: within the image being fused every source pixel q gets a time tau(q) = the raster index of
+// the first accepted pixel that masks it (-1: masked before this image, INT_MAX: never).  Given tau, every pixel t can be
+// evaluated independently -- source pixel q is masked for t exactly when tau(q) < t -- and yields its consistent source
+// pixels and its acceptance; the marks of an accepted pixel are the entries of the reference's used_list at that moment,
+// i.e. per source slot the pixel of the LATEST raster index <= t that was consistent with that slot (the list is never
+// reset between pixels, ref :382,:416,:470-495): an inclusive "last valid" scan in raster order.  The marks give a new tau;
+// iterate until it stops changing.  Each pass is right for at least one more pixel than the one before (a pixel only depends
+// on marks of earlier pixels), so the iteration ends at the unique fixpoint = the sequential result; real scenes need a
+// handful of passes.
 #pragma once
 
 #include "pm_device.hpp"
@@ -25,6 +36,8 @@ struct FuseView {
     const unsigned char* sky;    // optional sky mask (> 0 = sky, reference :385-388) or null
     unsigned char* mask;         // snapshot read by the kernel (written only at a thread's own sky pixel)
     unsigned char* mask_next;    // marks written by the kernel
+    int* tau;                    // exact mode: time of the first mark inside the image being fused (see above)
+    int* tau_new;                // exact mode: the same, as produced by the current pass
 };
 
 // reference src/PatchMatch.cpp:211-231
@@ -59,12 +72,21 @@ PM_DEV void load_color(const FuseView& V, size_t idx, float& c0, float& c1, floa
     }
 }
 
+// EXACT: consq[(j - 1) * N + t] receives, for every pixel t of the image and source slot j, the source pixel that was
+// consistent with t (or -1); out_valid is written for every pixel (0 / 1)
+template <bool EXACT>
 __global__ __launch_bounds__(256) void k_fuse(const FuseView* __restrict__ views, int i, const int* __restrict__ src_ids, int num_ngb,
-                                              int use_dynamic, unsigned char* __restrict__ out_valid, float* __restrict__ out9) {
+                                              int use_dynamic, unsigned char* __restrict__ out_valid, float* __restrict__ out9,
+                                              int* __restrict__ consq) {
     const FuseView& R = views[i];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = blockIdx.y * 8 + (threadIdx.x >> 5);
     if (c >= R.w || r >= R.h) return;
     const size_t pix = (size_t)r * R.w + c;
+    const size_t npix = (size_t)R.w * R.h;
+    if (EXACT) {
+        out_valid[pix] = 0;
+        for (int j = 1; j < num_ngb; ++j) consq[(size_t)(j - 1) * npix + pix] = -1;
+    }
     if (R.mask[pix] == 1) return;
     if (R.sky && R.sky[pix] > 0) {  // only this thread ever reads mask[pix] of the image being fused
         R.mask[pix] = 1;
@@ -93,7 +115,7 @@ __global__ __launch_bounds__(256) void k_fuse(const FuseView* __restrict__ views
         if (!round_index(v, sr) || !round_index(u, sc)) continue;
         if (!(sc >= 0 && sc < S.w && sr >= 0 && sr < S.h)) continue;
         const size_t sidx = (size_t)sr * S.w + sc;
-        if (S.mask[sidx] == 1) continue;
+        if (EXACT ? (S.tau[sidx] < (int)pix) : (S.mask[sidx] == 1)) continue;
         const float sd = S.depth[sidx];
         if (sd <= 0.0f) continue;
         const float m0 = S.normal[sidx * 3], m1 = S.normal[sidx * 3 + 1], m2 = S.normal[sidx * 3 + 2];
@@ -111,6 +133,7 @@ __global__ __launch_bounds__(256) void k_fuse(const FuseView* __restrict__ views
         if (angle != angle) angle = 0.0f;  // ref :233-242
         if (angle < 0.174533f) {
             used[j] = (int)sidx;
+            if (EXACT) consq[(size_t)(j - 1) * npix + pix] = (int)sidx;
             sp0 += T0;
             sp1 += T1;
             sp2 += T2;
@@ -141,8 +164,93 @@ __global__ __launch_bounds__(256) void k_fuse(const FuseView* __restrict__ views
     o[7] = sc1 / d;
     o[8] = sc2 / d;
     out_valid[pix] = 1;
-    for (int j = 1; j < num_ngb; ++j)
-        if (used[j] != -1) views[src_ids[j]].mask_next[used[j]] = 1;  // idempotent
+    if (!EXACT)
+        for (int j = 1; j < num_ngb; ++j)
+            if (used[j] != -1) views[src_ids[j]].mask_next[used[j]] = 1;  // idempotent
+}
+
+// ---------------------------------------------------------------------------
+// exact mode: the used_list of the reference as an inclusive "last valid entry" scan over the raster order, per source slot.
+// Pass 1 scans chunks of 256 pixels in place and records each chunk's last valid entry; pass 2 turns those into the entry
+// carried INTO each chunk; k_fuse_mark combines both.
+// ---------------------------------------------------------------------------
+PM_DEV int last_valid(int left, int right) { return right >= 0 ? right : left; }
+
+__global__ __launch_bounds__(256) void k_fuse_carry_local(int* __restrict__ consq, int npix, int nchunks, int* __restrict__ tails) {
+    const int slot = blockIdx.y, chunk = blockIdx.x, t = chunk * 256 + threadIdx.x;
+    int* row = consq + (size_t)slot * npix;
+    int v = t < npix ? row[t] : -1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(v, d, 64);
+        if (lane >= d) v = last_valid(up, v);
+    }
+    __shared__ int wave_tail[4];
+    if (lane == 63) wave_tail[wv] = v;
+    __syncthreads();
+    int carry = -1;
+    for (int k = 0; k < wv; ++k) carry = last_valid(carry, wave_tail[k]);
+    v = last_valid(carry, v);
+    if (t < npix) row[t] = v;
+    if (threadIdx.x == 255) tails[(size_t)slot * nchunks + chunk] = v;
+}
+
+// tails[slot][chunk] -> the entry carried into the chunk (exclusive scan with last_valid), in place; one block per slot
+__global__ __launch_bounds__(256) void k_fuse_carry_chunks(int* __restrict__ tails, int nchunks) {
+    int* row = tails + (size_t)blockIdx.x * nchunks;
+    __shared__ int part[256];
+    const int per = (nchunks + 255) / 256, lo = min((int)threadIdx.x * per, nchunks), hi = min(lo + per, nchunks);
+    int s = -1;
+    for (int k = lo; k < hi; ++k) s = last_valid(s, row[k]);
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = -1;
+        for (int k = 0; k < 256; ++k) {
+            const int c = part[k];
+            part[k] = run;
+            run = last_valid(run, c);
+        }
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int k = lo; k < hi; ++k) {
+        const int c = row[k];
+        row[k] = run;
+        run = last_valid(run, c);
+    }
+}
+
+// marks of the accepted pixels: tau_new(q) = min(tau_new(q), t) for every entry of the used_list at time t
+__global__ __launch_bounds__(256) void k_fuse_mark(const FuseView* __restrict__ views, const int* __restrict__ src_ids, int num_ngb,
+                                                   const unsigned char* __restrict__ out_valid, const int* __restrict__ consq,
+                                                   const int* __restrict__ carry, int npix, int nchunks) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= npix || !out_valid[t]) return;
+    for (int j = 1; j < num_ngb; ++j) {
+        int q = consq[(size_t)(j - 1) * npix + t];
+        if (q < 0) q = carry[(size_t)(j - 1) * nchunks + (t >> 8)];
+        if (q >= 0) atomicMin(&views[src_ids[j]].tau_new[q], t);
+    }
+}
+
+// tau0 from the masks of the earlier images: -1 = masked already, INT_MAX = free
+__global__ __launch_bounds__(256) void k_fuse_tau_init(const unsigned char* __restrict__ mask, int n, int* __restrict__ tau) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q < n) tau[q] = mask[q] == 1 ? -1 : 0x7fffffff;
+}
+// number of entries in which two tau arrays differ, added to *count
+__global__ __launch_bounds__(256) void k_fuse_tau_diff(const int* __restrict__ a, const int* __restrict__ b, int n, int* __restrict__ count) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const bool d = q < n && a[q] != b[q];
+    const unsigned long long m = __ballot(d);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (int)__popcll(m));
+}
+// the fixpoint's marks become masks for the following images
+__global__ __launch_bounds__(256) void k_fuse_tau_to_mask(const int* __restrict__ tau, int n, unsigned char* __restrict__ mask) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q < n && tau[q] != 0x7fffffff) mask[q] = 1;
 }
 
 // ---------------------------------------------------------------------------

@@ -27,7 +27,7 @@ _EXTRA = {
     "get_prior": (C.c_int, [_P, _P, _P]),
     "eval_ncc_multi": (C.c_int, [_P, C.POINTER(_abi.PatchMatchParams), _P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_float)]),
 }
-ALL_SYMBOLS = ["mpmvs_" + n for n in list(_abi.SIGNATURES) + list(_EXTRA)] + ["mpmvs_fuse", "mpmvs_fuse_kernel_ms", "mpmvs_sky_bilateral", "mpmvs_sky_kernel_ms", "mpmvs_fuse_ply", "mpmvs_free"]
+ALL_SYMBOLS = ["mpmvs_" + n for n in list(_abi.SIGNATURES) + list(_EXTRA)] + ["mpmvs_fuse", "mpmvs_fuse_kernel_ms", "mpmvs_fuse_passes", "mpmvs_sky_bilateral", "mpmvs_sky_kernel_ms", "mpmvs_fuse_ply", "mpmvs_free"]
 
 _cache = {}
 

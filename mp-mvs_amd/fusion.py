@@ -19,7 +19,10 @@ def _as_u8(x):
     return np.ascontiguousarray(x if x.dtype == np.uint8 else np.clip(np.rint(x), 0, 255).astype(np.uint8))
 
 
-def call_fuse(fn, lead_args, cams, estimate, depths, normals, colors, sources, use_dynamic=True, sky=None):
+FUSE_DYNAMIC_CONSISTENCY, FUSE_REFERENCE_ORDER = 1, 2   # include/mpmvs.h
+
+
+def call_fuse(fn, lead_args, cams, estimate, depths, normals, colors, sources, use_dynamic=True, sky=None, reference_order=False):
     """fn(*lead_args, n, cams, estimate, depths, normals, colors, channels, sky, src_off, src_ids, use_dynamic, valid, points9, masks)
     colors[k]: HxW grey or HxWx3 B,G,R (8 bit; floats are rounded); sky: None or per image None / HxW uint8 mask;
     sources[k] = source-view ids of image k (without k itself).  Returns
@@ -48,21 +51,33 @@ def call_fuse(fn, lead_args, cams, estimate, depths, normals, colors, sources, u
     fp = lambda arrs: (C.POINTER(C.c_float) * n)(*[a.ctypes.data_as(C.POINTER(C.c_float)) for a in arrs])
     up = lambda arrs: (C.POINTER(C.c_ubyte) * n)(*[a.ctypes.data_as(C.POINTER(C.c_ubyte)) for a in arrs])
     rc = fn(*lead_args, n, (Camera * n)(*cams), (C.c_int * n)(*[1 if e else 0 for e in estimate]), fp(d), fp(nm), up(g), cch, skyp,
-            (C.c_int * (n + 1))(*off), (C.c_int * len(ids))(*ids), 1 if use_dynamic else 0, up(valid), fp(pts), up(masks))
+            (C.c_int * (n + 1))(*off), (C.c_int * len(ids))(*ids),
+            (FUSE_DYNAMIC_CONSISTENCY if use_dynamic else 0) | (FUSE_REFERENCE_ORDER if reference_order else 0), up(valid), fp(pts), up(masks))
     if rc != 0:
         raise RuntimeError(f"fuse failed ({rc})")
     cloud = np.concatenate([p[v.astype(bool)] for p, v in zip(pts, valid)], 0) if n else np.zeros((0, 9), np.float32)
     return cloud, valid, masks
 
 
-def fuse(cams, estimate, depths, normals, colors, sources, use_dynamic=True, device=0, sky=None):
-    """fusion on the MI355X (mpmvs_fuse)"""
+def fuse(cams, estimate, depths, normals, colors, sources, use_dynamic=True, device=0, sky=None, reference_order=False):
+    """fusion on the MI355X (mpmvs_fuse); reference_order: the reference's sequential masking order instead of the snapshot formulation"""
     from . import engine
     lib, _ = engine.load()
     fn = lib.mpmvs_fuse
     fn.restype = C.c_int
     fn.argtypes = [C.c_int] + FUSE_ARGTYPES_TAIL
-    return call_fuse(fn, (int(device),), cams, estimate, depths, normals, colors, sources, use_dynamic, sky)
+    return call_fuse(fn, (int(device),), cams, estimate, depths, normals, colors, sources, use_dynamic, sky, reference_order)
+
+
+def fuse_passes():
+    """(total, max per image) fixpoint passes of the last reference_order call"""
+    from . import engine
+    lib, _ = engine.load()
+    lib.mpmvs_fuse_passes.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.mpmvs_fuse_passes.restype = None
+    a, b = C.c_int(0), C.c_int(0)
+    lib.mpmvs_fuse_passes(C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def ply_records(cloud):
@@ -80,7 +95,7 @@ def ply_records(cloud):
     return rec
 
 
-def fuse_ply(cams, estimate, depths, normals, colors, sources, use_dynamic=True, device=0, sky=None):
+def fuse_ply(cams, estimate, depths, normals, colors, sources, use_dynamic=True, device=0, sky=None, reference_order=False):
     """mpmvs_fuse_ply: fusion with device-side compaction; returns ([M, 27] uint8 PLY vertex records, masks list)"""
     from . import engine
     lib, _ = engine.load()
@@ -101,7 +116,7 @@ def fuse_ply(cams, estimate, depths, normals, colors, sources, use_dynamic=True,
         lib.mpmvs_free(rec)
         return 0
 
-    _, _, masks = call_fuse(call, (int(device),), cams, estimate, depths, normals, colors, sources, use_dynamic, sky)
+    _, _, masks = call_fuse(call, (int(device),), cams, estimate, depths, normals, colors, sources, use_dynamic, sky, reference_order)
     return out["records"], masks
 
 

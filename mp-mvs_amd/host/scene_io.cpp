@@ -498,6 +498,13 @@ int RefineSkyMasks(const std::string& input_folder, const std::vector<Scene>& Sc
 // the snapshot formulation of DESIGN.md section 8) and writes <output>/MPMVS_model.ply.
 // Returns the number of points, or -1.
 // ---------------------------------------------------------------------------
+// MPMVS_FUSE_ORDER=reference selects the reference's sequential masking order (a parallel fixpoint on the device, include/mpmvs.h
+// MPMVS_FUSE_REFERENCE_ORDER) instead of the default snapshot formulation
+static bool fuse_reference_order() {
+    const char* e = std::getenv("MPMVS_FUSE_ORDER");
+    return e && std::string(e) == "reference";
+}
+
 long RunFusion(const std::string& input_folder, const std::string& output_folder, std::vector<Scene>& Scenes, bool use_dynamic_consistency, int device,
                bool sky_seg) {
     const int n = (int)Scenes.size();
@@ -558,7 +565,9 @@ long RunFusion(const std::string& input_folder, const std::string& output_folder
     // reference's PointCloud vector): only they cross PCIe
     unsigned char* records = nullptr;
     const long long count = mpmvs_fuse_ply(device, n, cams.data(), estimate.data(), dp.data(), np_.data(), gp.data(), 3, sky_seg ? sp.data() : nullptr,
-                                           src_off.data(), src_ids.data(), use_dynamic_consistency ? 1 : 0, &records, nullptr);
+                                           src_off.data(), src_ids.data(),
+                                           (use_dynamic_consistency ? MPMVS_FUSE_DYNAMIC_CONSISTENCY : 0) | (fuse_reference_order() ? MPMVS_FUSE_REFERENCE_ORDER : 0),
+                                           &records, nullptr);
     if (count < 0) return -1;
     std::cout << "store 3D points to ply file" << std::endl;
     const std::string ply = output_folder + "/MPMVS_model.ply";

@@ -16,9 +16,8 @@ _cache = {}
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "pm_oracle.cpp")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    """make decides what is stale (both sources are prerequisites of liboracle.so)"""
+    subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []) + ["liboracle.so"], stdout=subprocess.DEVNULL)
     return _LIB
 
 
@@ -77,15 +76,16 @@ def eval_ncc_literal(handle, params, planes_cam, scale, quantize_fraction=False)
     return out
 
 
-def fuse(cams, estimate, depths, normals, colors, sources, use_dynamic=True, sequential_literal=False, sky=None):
-    """oracle fusion: mode 0 = the snapshot formulation the GPU implements, mode 1 = the
-    reference's literal sequential order (measurement only)"""
+def fuse(cams, estimate, depths, normals, colors, sources, use_dynamic=True, sequential_literal=False, sky=None, reference_order=False):
+    """oracle fusion: mode 0 = the snapshot formulation (the GPU's default), mode 1 = the reference's literal sequential
+    order with libm (measurement only), mode 2 (reference_order) = the sequential order in the canonical arithmetic = what
+    the GPU's MPMVS_FUSE_REFERENCE_ORDER mode computes"""
     fusion = importlib.import_module("mp-mvs_amd.fusion")
     l, _ = lib()
     fn = l.orc_fuse
     fn.restype = C.c_int
     fn.argtypes = [C.c_int] + fusion.FUSE_ARGTYPES_TAIL
-    return fusion.call_fuse(fn, (1 if sequential_literal else 0,), cams, estimate, depths, normals, colors, sources, use_dynamic, sky)
+    return fusion.call_fuse(fn, (1 if sequential_literal else (2 if reference_order else 0),), cams, estimate, depths, normals, colors, sources, use_dynamic, sky)
 
 
 def sky_bilateral(bgr, mask, literal=False):

@@ -16,6 +16,9 @@
 //          (ref :382,:416,:470-495), libm acosf/exp.  Only used to MEASURE how far the
 //          snapshot formulation is from the reference's order-dependent result.
 //
+//  mode 2  the same sequential order (in-place masks, persistent used_list) in the canonical arithmetic: what the GPU's
+//          MPMVS_FUSE_REFERENCE_ORDER mode must reproduce bit for bit (it computes it as a parallel fixpoint).
+//
 // PARITY UNPINNED against reference outputs, like the rest of the oracle.
 #include <cmath>
 #include <cstdint>
@@ -202,8 +205,8 @@ extern "C" int orc_fuse(int mode, int n, const void* cams_, const int* estimate,
     }
     int max_ngb = 1;
     for (int i = 0; i < n; ++i) max_ngb = std::max(max_ngb, src_off[i + 1] - src_off[i]);
-    if (mode == 1) {
-        // literal: masks updated in place, used_list persists across pixels of an image
+    if (mode == 1 || mode == 2) {
+        // sequential: masks updated in place, used_list persists across pixels of an image (mode 1: libm, mode 2: canonical math)
         for (int i = 0; i < n; ++i) {
             if (!estimate[i]) continue;
             const int rows = cams[i].height, cols = cams[i].width;
@@ -217,7 +220,7 @@ extern "C" int orc_fuse(int mode, int n, const void* cams_, const int* estimate,
                         continue;
                     }
                     float o[9];
-                    if (fuse_pixel<true>(V, i, r, c, masks, use_dynamic, o, used)) {
+                    if (mode == 1 ? fuse_pixel<true>(V, i, r, c, masks, use_dynamic, o, used) : fuse_pixel<false>(V, i, r, c, masks, use_dynamic, o, used)) {
                         out_valid[i][(size_t)r * cols + c] = 1;
                         std::memcpy(&out_points9[i][((size_t)r * cols + c) * 9], o, sizeof(o));
                         for (int j = 1; j < num_ngb; ++j)

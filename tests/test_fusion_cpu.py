@@ -108,3 +108,17 @@ def test_colour_and_sky_mask(pm, oracle):
     for k in range(6):
         if sky[k] is not None:
             assert valid_l[k][sky[k] > 0].sum() == 0 and masks_l[k][sky[k] > 0].all()
+
+
+def test_reference_order_in_canonical_arithmetic(pm, oracle):
+    """oracle mode 2 = the reference's sequential order (in-place masks, persistent used_list) in the canonical arithmetic: what
+    the GPU's MPMVS_FUSE_REFERENCE_ORDER mode reproduces.  Against the literal (libm) restatement of that loop only isolated
+    threshold decisions may flip; against the snapshot formulation the known few-percent deviation shows."""
+    sc, cams, depths, normals, grays, neigh = _scene(pm)
+    c1, v1, m1 = oracle.fuse(cams, [True] * 6, depths, normals, grays, neigh, sequential_literal=True)
+    c2, v2, m2 = oracle.fuse(cams, [True] * 6, depths, normals, grays, neigh, reference_order=True)
+    c0, v0, m0 = oracle.fuse(cams, [True] * 6, depths, normals, grays, neigh)
+    assert abs(len(c2) - len(c1)) <= 0.002 * len(c1)
+    assert np.mean([np.mean(a == b) for a, b in zip(v1, v2)]) > 0.998
+    assert len(c0) != len(c2)                      # the two formulations do differ on this scene
+    assert np.array_equal(v0[0], v2[0]) is False or np.array_equal(m0[1], m2[1]) is False

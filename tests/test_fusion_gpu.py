@@ -93,3 +93,32 @@ def test_fusion_rejects_view_ids_that_do_not_exist(pm, engine):
             fusion.fuse(cams, [True] * 6, depths, normals, grays, broken)
     cg, _, _ = fusion.fuse(cams, [True] * 6, depths, normals, grays, neigh)   # and the device is still usable afterwards
     assert len(cg) > 100
+
+
+@pytest.mark.parametrize("variant", ["dynamic", "static", "colour+sky"])
+def test_reference_order_fusion_bit_exact(pm, oracle, engine, variant):
+    """MPMVS_FUSE_REFERENCE_ORDER: the reference's order-dependent result (pixel-by-pixel in-place masks and the used_list that
+    is never reset, ref src/PatchMatch.cpp:382,416,470-495) computed on the GPU as a parallel fixpoint == the sequential loop of
+    the oracle (mode 2), bit for bit"""
+    fusion = importlib.import_module("mp-mvs_amd.fusion")
+    sc, cams, depths, normals, grays, neigh = _scene(pm, size=(160, 120))
+    depths[2][10:30, 20:60] = 0.0
+    cols, sky = grays, None
+    if variant == "colour+sky":
+        cols, sky = _colours_and_sky(grays)
+    dyn = variant != "static"
+    est = [True, True, False, True, True, True]
+    cg, vg, mg = fusion.fuse(cams, est, depths, normals, cols, neigh, dyn, sky=sky, reference_order=True)
+    total, worst = fusion.fuse_passes()
+    cc, vc, mc = oracle.fuse(cams, est, depths, normals, cols, neigh, dyn, sky=sky, reference_order=True)
+    assert len(cg) == len(cc) and len(cg) > 1000
+    assert np.array_equal(cg, cc)
+    assert all(np.array_equal(a, b) for a, b in zip(vg, vc)) and all(np.array_equal(a, b) for a, b in zip(mg, mc))
+    assert 5 <= total and 2 <= worst <= 200          # a fixpoint needs at least a confirming pass per image; chains stay short
+    print(f"reference-order fusion, {variant}: {total} passes over 5 images, at most {worst} for one image")
+    # and it is NOT the snapshot result (otherwise this test would prove nothing)
+    cs, vs, ms = fusion.fuse(cams, est, depths, normals, cols, neigh, dyn, sky=sky)
+    assert len(cs) != len(cg) or not all(np.array_equal(a, b) for a, b in zip(ms, mg))
+    # records path (device-side compaction) gives the same points
+    rec, _ = fusion.fuse_ply(cams, est, depths, normals, cols, neigh, dyn, sky=sky, reference_order=True)
+    assert np.array_equal(rec, fusion.ply_records(cg))

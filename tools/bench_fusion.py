@@ -18,10 +18,19 @@ cols = [np.stack([g, 255 - g, g // 2], -1).astype(np.uint8) for g in (np.asarray
 fusion.fuse_ply(cams, [True] * 8, depths, normals, cols, neigh)
 t0 = time.perf_counter(); rec, _ = fusion.fuse_ply(cams, [True] * 8, depths, normals, cols, neigh); tp = time.perf_counter() - t0
 kms_ply = fusion.last_kernel_ms()
+# the reference's sequential order as a parallel fixpoint (MPMVS_FUSE_REFERENCE_ORDER)
+fusion.fuse_ply(cams, [True] * 8, depths, normals, cols, neigh, reference_order=True)
+t0 = time.perf_counter(); rec_ref, _ = fusion.fuse_ply(cams, [True] * 8, depths, normals, cols, neigh, reference_order=True); tr = time.perf_counter() - t0
+kms_ref = fusion.last_kernel_ms()
+passes = fusion.fuse_passes()
+t0 = time.perf_counter(); cr, vr, mr = ob.fuse(cams, [True] * 8, depths, normals, cols, neigh, reference_order=True); tro = time.perf_counter() - t0
+ref_exact = bool(np.array_equal(rec_ref, fusion.ply_records(cr)))
 ob.set_num_threads(min(16, len(os.sched_getaffinity(0))))
 t0 = time.perf_counter(); cc, vc, mc = ob.fuse(cams, [True] * 8, depths, normals, grays, neigh); tc = time.perf_counter() - t0
 t0 = time.perf_counter(); cs, vs, ms = ob.fuse(cams, [True] * 8, depths, normals, grays, neigh, sequential_literal=True); ts = time.perf_counter() - t0
-print(json.dumps({"fuse_ply_bgr_incl_transfers_s": round(tp, 3), "fuse_ply_kernels_ms": round(kms_ply, 3), "fuse_ply_points": int(len(rec)), "images": 8, "size": [1600, 1200], "points": int(len(cg)), "gpu_incl_transfers_s": round(tg, 3), "oracle_snapshot_16thr_s": round(tc, 3),
+print(json.dumps({"reference_order": {"fuse_ply_incl_transfers_s": round(tr, 3), "kernels_ms": round(kms_ref, 3), "points": int(len(rec_ref)), "passes_total": passes[0],
+                                      "passes_max_per_image": passes[1], "oracle_sequential_1thr_s": round(tro, 3), "records_equal_sequential_oracle": ref_exact},
+                  "fuse_ply_bgr_incl_transfers_s": round(tp, 3), "fuse_ply_kernels_ms": round(kms_ply, 3), "fuse_ply_points": int(len(rec)), "images": 8, "size": [1600, 1200], "points": int(len(cg)), "gpu_incl_transfers_s": round(tg, 3), "oracle_snapshot_16thr_s": round(tc, 3),
                   "oracle_sequential_literal_s": round(ts, 3), "bit_exact": bool(np.array_equal(cg, cc)), "points_sequential": int(len(cs)),
                   "Mpix_per_s_gpu": round(8 * 1600 * 1200 / tg / 1e6, 1), "gpu_kernels_ms": round(kms, 3),
                   "algorithmic_GB": round(8 * 1600 * 1200 * (21 + 7 * 21 + 37) / 1e9, 2), "GBps_kernels": round(8 * 1600 * 1200 * (21 + 7 * 21 + 37) / (kms * 1e-3) / 1e9, 1)}))
