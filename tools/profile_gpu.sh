@@ -1,17 +1,25 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): kernel trace + separate PMC passes of one bench step.
-# usage: tools/profile_gpu.sh <tag>      -> gpurun_out/prof_<tag>/
+# Run on the GPU box (via gpurun): kernel trace + separate PMC passes of one command (default: one bench step).
+# usage: tools/profile_gpu.sh <tag> [python-script args...]   -> gpurun_out/prof_<tag>/
+#   tools/profile_gpu.sh r02a                                  bench.py cfg 1 (fp16 textures)
+#   tools/profile_gpu.sh r02f32 bench.py --float-images ...    the same with fp32 textures
+# Each counter group runs in its own rocprofv3 process together with --kernel-trace only (never with other trace domains);
+# the program itself follows `--`.
 set -o pipefail
 TAG=${1:-r1}
+shift
+if [ $# -eq 0 ]; then set -- bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary; fi
+cd ${GRAFT_REPO_ROOT:?}
 export OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:?}
-python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary > $OUT/bench_plain.json 2>/dev/null   # also fills the scene cache
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/bench_traced.json 2> $OUT/trace.err
+python3 "$@" > $OUT/plain.json 2>/dev/null   # also fills the scene cache
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 "$@" > $OUT/traced.json 2> $OUT/trace.err
 pass() { # name, counters...
   n=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_$n -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary > /dev/null 2> $OUT/pmc_$n.err || echo "pmc pass $n failed" >> $OUT/errors.txt
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_$n -- python3 "${CMD[@]}" > /dev/null 2> $OUT/pmc_$n.err || echo "pmc pass $n failed" >> $OUT/errors.txt
 }
+CMD=("$@")
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
 pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_INSTS_LDS SQ_WAIT_INST_LDS
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum
@@ -20,4 +28,5 @@ pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
 python3 tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+python3 tools/summarize_trace.py $OUT/trace > $OUT/trace_summary.txt 2>&1
 cat $OUT/summary.txt

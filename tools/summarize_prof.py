@@ -11,7 +11,7 @@ out = sys.argv[1]
 
 
 def short(name):
-    for key in ("k_update", "k_init", "k_filter", "k_depth_normal", "k_pad", "k_export", "k_eval"):
+    for key in ("k_update", "k_init", "k_filter", "k_depth_normal", "k_pad", "k_export", "k_eval", "k_prior_raster", "k_prior"):
         if key in name:
             return key
     return name[:40]
