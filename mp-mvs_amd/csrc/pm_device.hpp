@@ -446,8 +446,23 @@ PM_DEV int tex_byte_offset(const TEX& t, int iy, int ix) {
 //     in fp16, v_fma_mix_f32 reads the half operands directly and rounds once in fp32: identical bits to the fp32 format.
 // The 128-bit buffer resource is wave-uniform (built from scalar loads); the 32-bit byte offset is range checked by the
 // hardware (an out-of-range offset -- impossible, the coordinate is clamped first -- would read 0 instead of faulting).
+// The gather addresses a texel by its INDEX (buffer_load ... idxen, the descriptor carries the texel size as its stride),
+// so the address is one v_mad_u32_u24 instead of a 24-bit multiply and a shift-add (-1.2 % on k_update; -DPM_NO_IDXEN
+// builds the byte-offset form).  The descriptor is written out as four dwords because the indexed load is reached through
+// its LLVM intrinsic (hipcc has no builtin for it); an index beyond `texels` reads 0 (cannot happen: clamped coordinates).
+typedef int i32x4q __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2q __attribute__((ext_vector_type(2)));
+typedef float f32x4q __attribute__((ext_vector_type(4)));
+__device__ u32x2q pm_struct_load_b64(i32x4q rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v2i32");
+__device__ f32x4q pm_struct_load_f128(i32x4q rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v4f32");
+PM_DEV i32x4q make_indexed_rsrc(const void* base, int texel_bytes, int texels) {
+    const unsigned long long a = (unsigned long long)base;
+    return (i32x4q){(int)(unsigned)a, (int)(((unsigned)(a >> 32) & 0xffffu) | ((unsigned)texel_bytes << 16)), texels, 0x00020000};
+}
+
 struct SrcTex {
     __amdgpu_buffer_rsrc_t rsrc;
+    i32x4q irsrc;
     int pitch;  // texels per row (= w)
     float wm1, hm1;
 };
@@ -459,11 +474,13 @@ PM_DEV SrcTex make_src_tex(const ViewDev& vw) {
     t.hm1 = vw.hm1;
     const int bytes = vw.pitch * vw.h * 16;
     t.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vw.img), (short)0, bytes, 0x00020000);
+    t.irsrc = make_indexed_rsrc(vw.img, 16, vw.pitch * vw.h);
     return t;
 }
 
 struct SrcTex8 {
     __amdgpu_buffer_rsrc_t rsrc;
+    i32x4q irsrc;
     int pitch;  // texels per row (= w)
     float wm1, hm1;
 };
@@ -475,6 +492,7 @@ PM_DEV SrcTex8 make_src_tex8(const ViewDev& vw) {
     t.hm1 = vw.hm1;
     const int bytes = vw.pitch8 * vw.h * 8;
     t.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(vw.img8), (short)0, bytes, 0x00020000);
+    t.irsrc = make_indexed_rsrc(vw.img8, 8, vw.pitch8 * vw.h);
     return t;
 }
 
@@ -484,8 +502,6 @@ PM_DEV SrcTex8 make_src_tex8(const ViewDev& vw) {
 template <bool U8>
 struct BilinearTap;
 
-typedef float f32x4q __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2q __attribute__((ext_vector_type(2)));
 template <>
 struct BilinearTap<false> {
     float ax, ay;
@@ -496,6 +512,12 @@ struct BilinearTap<false> {
         const float cy = clamp_coord(sy, t.hm1);
         ax = __builtin_amdgcn_fractf(cx);  // v_fract_f32: x - floor(x), kept below 1
         ay = __builtin_amdgcn_fractf(cy);
+#if !defined(PM_NO_IDXEN) && !defined(PM_DBG_NOLOAD) && !defined(PM_DBG_ADDRMASK)
+        if constexpr (!__is_same(TEX, LaneTex)) {
+            q = pm_struct_load_f128(t.irsrc, (int)(__umul24((unsigned)floor_to_int(cy), (unsigned)t.pitch) + (unsigned)floor_to_int(cx)), 0, 0, 0);
+            return;
+        }
+#endif
         const int off = tex_byte_offset<4>(t, floor_to_int(cy), floor_to_int(cx));
 #ifdef PM_DBG_NOLOAD  // measurement builds only (results are wrong): the instruction stream without its gathers
         q = (f32x4q){(float)off, 1.0f, ax, ay};
@@ -519,6 +541,12 @@ struct BilinearTap<true> {
         const float cy = clamp_coord(sy, t.hm1);
         ax = __builtin_amdgcn_fractf(cx);
         ay = __builtin_amdgcn_fractf(cy);
+#if !defined(PM_NO_IDXEN) && !defined(PM_DBG_NOLOAD) && !defined(PM_DBG_ADDRMASK)
+        if constexpr (!__is_same(TEX, LaneTex)) {
+            q = pm_struct_load_b64(t.irsrc, (int)(__umul24((unsigned)floor_to_int(cy), (unsigned)t.pitch) + (unsigned)floor_to_int(cx)), 0, 0, 0);
+            return;
+        }
+#endif
         const int off = tex_byte_offset<3>(t, floor_to_int(cy), floor_to_int(cx));
 #ifdef PM_DBG_NOLOAD  // measurement builds only (results are wrong): the instruction stream without its gathers
         q = (u32x2q){(uint32_t)off, (uint32_t)off};

@@ -211,6 +211,23 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_init(const ProblemDe
     S.sel[idx] = sel;
 }
 
+// Which variants park the refinement ingredients and the candidate costs in private memory: those that would otherwise spill
+// around the evaluations (fp32 texels with the planar prior, or with the geometric term above 16 views).  Measured per variant
+// (gpurun_out/r2l): parking costs the non-spilling variants 1-4 %, and gains the spilling ones 3-6 %.
+#ifndef PM_PARK_WHEN
+#define PM_PARK_WHEN (!U8 && (PRIOR || (GEOM && MAXV > 16)))
+#endif
+// A private array that has to live in private MEMORY (plain loads and stores, scheduled like any others) instead of being
+// promoted to registers: its address is shown to an empty asm statement.
+PM_DEV void keep_in_memory(float* p) { asm volatile("" : : "v"(p)); }
+
+// An index whose address arithmetic has to stay where it is used: without this the 64-bit addresses of the eight neighbour
+// planes are formed once, ahead of the slot loop, and then spilled around the evaluations.
+PM_DEV int pinned_here(int i) {
+    asm volatile("" : "+v"(i));
+    return i;
+}
+
 PM_DEV float prior_term_body(float depth_diff, float angle_cos, float two_ds2, float two_as2) {
     const float ad = d_acos(angle_cos);
     return 0.5f + d_exp(-depth_diff * depth_diff / two_ds2) * d_exp(-ad * ad / two_as2);
@@ -235,6 +252,11 @@ template <bool GEOM, bool PRIOR, int MAXV, bool U8>
 __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
     const ProblemDev& P = *Pp;
     constexpr bool kGeomCall = MAXV > 8;  // see geom_cost_view
+#ifdef PM_PARK_ALL
+    constexpr bool kPark = true;
+#else
+    constexpr bool kPark = PM_PARK_WHEN;
+#endif
     int x, y, x0, y0;
     const bool valid = checker_pixel<U8>(P, a, x, y, x0, y0);
     const int step = 2 << a.scale, radius = 5 * step / 2;
@@ -291,10 +313,21 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
     const float two_as2 = (2.0f * angle_sigma) * angle_sigma;
     const float beta = 0.18f;
 
-    float4 plane_now = cur, base_n = cur, n_rand = cur, n_pert = cur, pp = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 plane_now = cur, pp = make_float4(0.f, 0.f, 0.f, 0.f);
     float depth_now = 0.0f, cost_now = 0.0f, geom_now = 0.0f, restricted_cost = 0.0f, weight_norm = 0.0f;
-    float depth_rand = 0.0f, depth_pert = 0.0f, depth_prior = 0.0f, cand_depth = 0.0f;
-    float final_costs[8];
+    float depth_prior = 0.0f, cand_depth = 0.0f;
+    // The ingredients of the five refinement candidates are drawn together (the order of the random draws is the
+    // reference's) but consumed one evaluation at a time: they wait in private memory, not in registers that the
+    // evaluations in between would have to spill.  Normals: 0 = current plane, 1 = random, 2 = perturbed; depths:
+    // 0 = current, 1 = random, 2 = perturbed.
+    float park_n[9];
+    float park_d[3];
+    float final_costs[8];  // written after phase A, read again only after the evaluation of slot 8: parked as well
+    if (kPark) {
+        keep_in_memory(park_n);
+        keep_in_memory(park_d);
+        keep_in_memory(final_costs);
+    }
     uint32_t temp_sel = 0;
     int min_idx = 0;
     bool masked = false;
@@ -324,10 +357,11 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
     {
     // ---- view weights (ref .cu:821-878)
     uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    if (flags & 1u) s0 = S.sel[idx - W];
-    if (flags & 2u) s1 = S.sel[idx + W];
-    if (flags & 4u) s2 = S.sel[idx - 1];
-    if (flags & 8u) s3 = S.sel[idx + 1];
+    const int idx_w = pinned_here(idx);
+    if (flags & 1u) s0 = S.sel[idx_w - W];
+    if (flags & 2u) s1 = S.sel[idx_w + W];
+    if (flags & 4u) s2 = S.sel[idx_w - 1];
+    if (flags & 8u) s3 = S.sel[idx_w + 1];
     float psum = 0.0f;
     for (int v = 0; v < V; ++v) {
         float vp = 0.0f;
@@ -367,6 +401,7 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
             weight_norm += view_w[v];
         }
     // ---- weighted candidate costs (ref .cu:880-899)
+    float fcv[8];
     for (int i = 0; i < 8; ++i) {
         const bool fl = (flags >> i) & 1u;
         GeomPoint gp{0.f, 0.f, 0.f};
@@ -384,13 +419,15 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
                 }
             }
         }
-        final_costs[i] = fc / weight_norm;
+        const float fci = fc / weight_norm;
+        final_costs[i] = fci;
+        fcv[i] = fci;
     }
     {
-        float mc = final_costs[0];
+        float mc = fcv[0];
         for (int i = 1; i < 8; ++i)
-            if (final_costs[i] <= mc) {
-                mc = final_costs[i];
+            if (fcv[i] <= mc) {
+                mc = fcv[i];
                 min_idx = i;
             }
     }
@@ -407,8 +444,9 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
             if (slot == 9) {
                 // ---- acceptance of the best propagated neighbour (ref .cu:921-991)
                 depth_now = depth_from_plane(P, cur, x, y);
-                if (PRIOR) pp = S.prior[idx];
-                masked = PRIOR && S.mask[idx] > 0;
+                const int idx_a = pinned_here(idx);
+                if (PRIOR) pp = S.prior[idx_a];
+                masked = PRIOR && S.mask[idx_a] > 0;
                 if (PRIOR && !GEOM) {
                     depth_prior = depth_from_plane(P, pp, x, y);
                     if (masked) {
@@ -416,11 +454,12 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
                         for (int i = 0; i < 8; ++i) {
                             rfc[i] = 0.0f;
                             if ((flags >> i) & 1u) {
-                                const float4 cpl = S.planes[pos[i]];
+                                const float4 cpl = S.planes[pinned_here(pos[i])];
                                 const float di = depth_from_plane(P, cpl, x, y);
                                 const float ac = (pp.x * cpl.x + pp.y * cpl.y) + pp.z * cpl.z;
                                 const float pr = prior_term<kGeomCall>(di - depth_prior, ac, two_ds2, two_as2);
-                                rfc[i] = d_exp(-final_costs[i] * final_costs[i] / beta) * pr;
+                                const float fci = final_costs[i];
+                                rfc[i] = d_exp(-fci * fci / beta) * pr;
                             }
                         }
                         int max_idx = 0;
@@ -434,17 +473,17 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
                         const float pr = prior_term<kGeomCall>(depth_now - depth_prior, ac, two_ds2, two_as2);
                         const float rc_now = d_exp(-cost_now * cost_now / beta) * pr;
                         if ((flags >> max_idx) & 1u) {
-                            const float4 cpl = S.planes[pos[max_idx]];
+                            const float4 cpl = S.planes[pinned_here(pos[max_idx])];
                             const float db = depth_from_plane(P, cpl, x, y);
                             if (db >= a.depth_min && db <= a.depth_max && rfc[max_idx] > rc_now) {
                                 // ref .cu:950/961: the shadowed depth_now keeps the old plane's depth
                                 plane_now = cpl;
                                 restricted_cost = rfc[max_idx];
-                                S.sel[idx] = temp_sel;
+                                S.sel[idx_a] = temp_sel;
                             }
                         }
                     } else if ((flags >> min_idx) & 1u) {
-                        const float4 cpl = S.planes[pos[min_idx]];
+                        const float4 cpl = S.planes[pinned_here(pos[min_idx])];
                         const float db = depth_from_plane(P, cpl, x, y);
                         if (db >= a.depth_min && db <= a.depth_max && final_costs[min_idx] < cost_now) {
                             depth_now = db;
@@ -453,18 +492,21 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
                     }
                 }
                 if (!PRIOR && ((flags >> min_idx) & 1u)) {
-                    const float4 cpl = S.planes[pos[min_idx]];
+                    const float4 cpl = S.planes[pinned_here(pos[min_idx])];
                     const float db = depth_from_plane(P, cpl, x, y);
                     if (db >= a.depth_min && db <= a.depth_max && final_costs[min_idx] < cost_now) {
                         depth_now = db;
                         plane_now = cpl;
                         cost_now = final_costs[min_idx];
-                        S.sel[idx] = temp_sel;
+                        S.sel[idx_a] = temp_sel;
                     }
                 }
                 // ---- refinement candidates (ref .cu:644-675)
                 const float perturbation = 0.02f;
+                float depth_rand;
+                float4 n_rand;
                 if (masked) {
+                    // ref .cu:651-660: the prior-guided draw is overwritten below (missing else), its random numbers are still consumed
                     depth_prior = depth_from_plane(P, pp, x, y);
                     depth_rand = (rng_uniform(g) * 6.0f) * depth_sigma + (depth_prior - 3.0f * depth_sigma);
                     n_rand = perturbed_normal(P, x, y, pp, g, angle_sigma);
@@ -473,14 +515,18 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
                 n_rand = random_normal(P, x, y, g);
                 const float dmin_p = (1.0f - perturbation) * depth_now;
                 const float dmax_p = (1.0f + perturbation) * depth_now;
-                depth_pert = rng_uniform(g) * (dmax_p - dmin_p) + dmin_p;
-                n_pert = perturbed_normal(P, x, y, plane_now, g, 0.06283185f);
-                base_n = plane_now;
+                const float depth_pert = rng_uniform(g) * (dmax_p - dmin_p) + dmin_p;
+                const float4 n_pert = perturbed_normal(P, x, y, plane_now, g, 0.06283185f);
+                park_n[0] = plane_now.x, park_n[1] = plane_now.y, park_n[2] = plane_now.z;
+                park_n[3] = n_rand.x, park_n[4] = n_rand.y, park_n[5] = n_rand.z;
+                park_n[6] = n_pert.x, park_n[7] = n_pert.y, park_n[8] = n_pert.z;
+                park_d[0] = depth_now, park_d[1] = depth_rand, park_d[2] = depth_pert;
             }
             // candidates: (d_rand,n) (d,n_rand) (d_rand,n_rand) (d,n_pert) (d_pert,n)   ref .cu:674-675
             const int ci = slot - 9;
-            pl = (ci == 1 || ci == 2) ? n_rand : (ci == 3 ? n_pert : base_n);
-            cand_depth = (ci == 0 || ci == 2) ? depth_rand : (ci == 4 ? depth_pert : depth_now);
+            const int ni = 3 * ((ci == 1 || ci == 2) ? 1 : (ci == 3 ? 2 : 0));
+            pl.x = park_n[ni], pl.y = park_n[ni + 1], pl.z = park_n[ni + 2];
+            cand_depth = park_d[(ci == 0 || ci == 2) ? 1 : (ci == 4 ? 2 : 0)];
             pl.w = plane_offset(P, x, y, cand_depth, pl);
         }
 
@@ -522,9 +568,10 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
             }
         }
     }
-    S.costs[idx] = cost_now;
-    S.planes[idx] = plane_now;
-    if (GEOM) S.geom[idx] = geom_now;
+    const int idx_o = pinned_here(idx);
+    S.costs[idx_o] = cost_now;
+    S.planes[idx_o] = plane_now;
+    if (GEOM) S.geom[idx_o] = geom_now;
 }
 
 // ---------------------------------------------------------------------------

@@ -68,6 +68,7 @@ struct Rect {
 // reference include/PatchMatch.h:69-72
 struct Triangle {
     Point pt1, pt2, pt3;
+    Triangle() {}
     Triangle(const Point a, const Point b, const Point c) : pt1(a), pt2(b), pt3(c) {}
 };
 
@@ -185,8 +186,9 @@ namespace mpmvs_host {
 // reference src/PatchMatch.cpp:782-853
 void TriangulateVertices(int width, int height, const float* costs, const float* geom_costs, bool geomPlanarPrior,
                          std::vector<Point>& Vertices);
-// reference src/PatchMatch.cpp:757-780 (cv::Subdiv2D replaced by an exact incremental Delaunay)
+// reference src/PatchMatch.cpp:757-780 (cv::Subdiv2D replaced by an exact divide-and-conquer Delaunay, parallel on the host)
 std::vector<Triangle> Delaunay(const Rect boundRC, const std::vector<Point>& points);
+long long DelaunayXY(const int* xy, size_t count, int* tri_xy, size_t cap);
 // reference src/PatchMatch.cpp:723-755 (cv::SVD::solveZ of three points = the plane through them)
 float4 PriorPlane(const Camera& cam, const Triangle& t, const float4* planes, int width);
 // reference src/PatchMatch.cpp:554-595: rasterise the triangles into a label mask, fit planes,

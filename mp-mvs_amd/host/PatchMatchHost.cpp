@@ -469,18 +469,10 @@ int mpmvs_host_triangulate_vertices(int w, int h, const float* costs, const floa
 
 // triangles -> out_xy (6 ints each); returns the count
 int mpmvs_host_delaunay(int w, int h, const int* xy, int n, int* out_xy, int cap) {
-    std::vector<Point> pts;
-    for (int i = 0; i < n; ++i) pts.push_back(Point(xy[2 * i], xy[2 * i + 1]));
-    const auto tris = mpmvs_host::Delaunay(Rect{0, 0, w, h}, pts);
-    for (size_t i = 0; i < tris.size() && (int)i < cap; ++i) {
-        out_xy[6 * i + 0] = tris[i].pt1.x;
-        out_xy[6 * i + 1] = tris[i].pt1.y;
-        out_xy[6 * i + 2] = tris[i].pt2.x;
-        out_xy[6 * i + 3] = tris[i].pt2.y;
-        out_xy[6 * i + 4] = tris[i].pt3.x;
-        out_xy[6 * i + 5] = tris[i].pt3.y;
-    }
-    return (int)tris.size();
+    (void)w;
+    (void)h;
+    if (n < 0 || cap < 0) return -1;
+    return (int)mpmvs_host::DelaunayXY(xy, (size_t)n, out_xy, (size_t)cap);
 }
 
 // the whole host prior construction of ProcessProblem (reference src/PatchMatch.cpp:532-604)

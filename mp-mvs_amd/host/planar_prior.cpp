@@ -5,7 +5,7 @@
 //   plane fit  reference src/PatchMatch.cpp:723-755  (cv::SVD::solveZ there)
 //   raster     reference src/PatchMatch.cpp:554-595
 // OpenCV is absent from the target image, so the triangulation is an own
-// incremental Bowyer-Watson with exact integer predicates, and the 3-point
+// divide-and-conquer Delaunay with exact integer predicates, and the 3-point
 // null-space solve is the closed form (cross product).  Parity note: for point
 // sets with four or more cocircular points (common on a pixel grid) the Delaunay
 // triangulation is not unique and cv::Subdiv2D's choice, as well as its triangle
@@ -15,6 +15,14 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <pthread.h>
+#include <sched.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <thread>
 #include <vector>
 
 #include "PatchMatch.h"
@@ -105,198 +113,404 @@ void TriangulateVertices(int width, int height, const float* costs, const float*
 }
 
 // ---------------------------------------------------------------------------
-// Delaunay triangulation: incremental Bowyer-Watson, exact 128-bit predicates
+// Delaunay triangulation: divide and conquer with alternating cuts, exact integer predicates, parallel subtrees.
+//
+// The point set is halved at the median along x, the halves along y, and so on (pieces stay roughly square, so a merge only
+// touches the edges next to its seam).  Pieces of two or three points are built directly; two triangulated halves are zipped
+// together from their lower common tangent upwards, deleting the edges of either side that fail the empty-circle test
+// against the other side (Guibas & Stolfi 1985, with Dwyer's 1987 alternation of the cut direction).  A cut along y is the
+// same procedure in the frame rotated by -90 degrees, (u, v) = (y, -x): orientation and in-circle tests do not change under
+// a rotation, only the ORDER of the points (y ascending, ties x descending) and the two hull edges a piece hands to its
+// parent do, and the latter are found by a walk around the piece's hull.
+//
+// Mesh: directed half-edges 2k / 2k+1 of edge k, each with its origin and its counter-clockwise / clockwise neighbour around
+// that origin.  The piece of points [l, r) owns the edge slots [3l, 3r) (a planar graph on n points has fewer than 3n edges),
+// so subtrees never share memory and the top levels of the recursion run on their own threads; the result -- triangles listed
+// by their lowest half-edge -- does not depend on the number of threads.
+// Cocircular quadruples (common on a pixel grid) keep whichever diagonal the zip meets first: a valid Delaunay triangulation,
+// deterministic, not necessarily cv::Subdiv2D's choice (see the parity note at the top).
 // ---------------------------------------------------------------------------
 namespace {
 typedef __int128 i128;
 
-struct Tri {
-    int v[3];  // counter-clockwise
-    int n[3];  // n[i]: neighbour across the edge opposite v[i]
+// Worker threads are placed explicitly: on the target hosts (micro-VM kernels) freshly created threads stay on their
+// creator's CPU for tens of milliseconds -- longer than the whole triangulation -- so a pool that relies on the scheduler's
+// load balancing runs serialised.  Each call takes a different stretch of the allowed CPUs (several Problems triangulate at
+// once in the multi-Problem schedule); the caller's thread is put on the first CPU of the stretch and restored afterwards.
+struct CpuPlacement {
+    std::vector<int> allowed;
+    cpu_set_t original;
+    int base = 0;
+    bool moved = false;
+    CpuPlacement() {
+        CPU_ZERO(&original);
+        if (sched_getaffinity(0, sizeof(original), &original) == 0)
+            for (int i = 0; i < CPU_SETSIZE; ++i)
+                if (CPU_ISSET(i, &original)) allowed.push_back(i);
+    }
+    void pin(int slot) const {
+        if (allowed.size() < 2) return;
+        cpu_set_t one;
+        CPU_ZERO(&one);
+        CPU_SET(allowed[(size_t)(base + slot) % allowed.size()], &one);
+        pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+    }
+    void enter(int threads) {
+        static std::atomic<unsigned> calls{0};
+        if (threads < 2 || allowed.size() < 2) return;
+        base = (int)((calls.fetch_add(1) * (unsigned)threads) % allowed.size());
+        pin(0);
+        moved = true;
+    }
+    ~CpuPlacement() {
+        if (moved) pthread_setaffinity_np(pthread_self(), sizeof(original), &original);
+    }
 };
 
-struct Mesh {
-    std::vector<long long> px, py;
-    std::vector<Tri> tris;
-    std::vector<char> dead;
-    int last = 0;
-    // scratch reused across inserts (no allocation in the steady state)
-    struct Edge {
-        int a, b, outer, tri;
-    };
-    std::vector<int> cavity, stack;
-    std::vector<Edge> edges;
+struct Zipper {
+    const CpuPlacement* cpus = nullptr;
+    const Point* P;
+    bool wide;  // coordinates span 2^13 or more: the in-circle determinant needs 128 bits
+    // not value-initialised: every piece sets up its own slots, so the pages are first touched by the thread that uses them
+    std::unique_ptr<int[]> next, prev, org, ids;
+    int par_depth = 0;
 
-    // vertices 0..2 are the far-away super triangle: only predicates touching them
-    // need 128 bits, image points (|coord| < 2^15) fit the 64-bit fast path exactly
-    i128 orient(int a, int b, int c) const {
-        if (a >= 3 && b >= 3 && c >= 3)
-            return (i128)((px[b] - px[a]) * (py[c] - py[a]) - (py[b] - py[a]) * (px[c] - px[a]));
-        return (i128)(px[b] - px[a]) * (py[c] - py[a]) - (i128)(py[b] - py[a]) * (px[c] - px[a]);
+    struct Piece {
+        int le, re;              // ccw hull edge out of the first point / cw hull edge out of the last point (in the piece's order)
+        int free_head, free_tail;  // unused edge slots of the piece, linked through next[]
+    };
+
+    static int sym(int e) { return e ^ 1; }
+    int dest(int e) const { return org[e ^ 1]; }
+    int lnext(int e) const { return prev[e ^ 1]; }
+    int rprev(int e) const { return next[e ^ 1]; }
+
+    long long ccw(int a, int b, int c) const {
+        return (long long)(P[b].x - P[a].x) * (P[c].y - P[a].y) - (long long)(P[b].y - P[a].y) * (P[c].x - P[a].x);
     }
-    // > 0: d strictly inside the circumcircle of counter-clockwise (a, b, c)
-    bool incircle_pos(int a, int b, int c, int d) const {
-        if (a >= 3 && b >= 3 && c >= 3 && d >= 3) {
-            const long long ax = px[a] - px[d], ay = py[a] - py[d];
-            const long long bx = px[b] - px[d], by = py[b] - py[d];
-            const long long cx = px[c] - px[d], cy = py[c] - py[d];
-            const long long a2 = ax * ax + ay * ay, b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
-            return ax * (by * c2 - b2 * cy) - ay * (bx * c2 - b2 * cx) + a2 * (bx * cy - by * cx) > 0;
+    bool left_of(int p, int e) const { return ccw(p, org[e], dest(e)) > 0; }
+    bool right_of(int p, int e) const { return ccw(p, dest(e), org[e]) > 0; }
+    // d strictly inside the circle through the counter-clockwise triangle (a, b, c)
+    bool in_circle(int a, int b, int c, int d) const {
+        const long long ax = P[a].x - P[d].x, ay = P[a].y - P[d].y, bx = P[b].x - P[d].x, by = P[b].y - P[d].y, cx = P[c].x - P[d].x,
+                        cy = P[c].y - P[d].y;
+        const long long a2 = ax * ax + ay * ay, b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
+        if (!wide) return ax * (by * c2 - b2 * cy) - ay * (bx * c2 - b2 * cx) + a2 * (bx * cy - by * cx) > 0;
+        return (i128)ax * (by * c2 - b2 * cy) - (i128)ay * (bx * c2 - b2 * cx) + (i128)a2 * (bx * cy - by * cx) > 0;
+    }
+    // order of the points along the cut direction: axis 0 = (x, then y), axis 1 = (y, then -x)
+    bool before(int axis, int a, int b) const {
+        if (axis == 0) return P[a].x != P[b].x ? P[a].x < P[b].x : P[a].y < P[b].y;
+        return P[a].y != P[b].y ? P[a].y < P[b].y : P[a].x > P[b].x;
+    }
+
+    void splice(int a, int b) {
+        const int an = next[a], bn = next[b];
+        next[a] = bn;
+        next[b] = an;
+        prev[bn] = a;
+        prev[an] = b;
+    }
+    int make_edge(Piece& pc, int o, int d) {
+        const int e = pc.free_head;
+        pc.free_head = next[e];
+        if (pc.free_head < 0) pc.free_tail = -1;
+        next[e] = prev[e] = e;
+        next[e ^ 1] = prev[e ^ 1] = e ^ 1;
+        org[e] = o;
+        org[e ^ 1] = d;
+        return e;
+    }
+    void release(Piece& pc, int e) {
+        e &= ~1;
+        org[e] = org[e ^ 1] = -1;
+        next[e] = pc.free_head;
+        if (pc.free_head < 0) pc.free_tail = e;
+        pc.free_head = e;
+    }
+    int connect(Piece& pc, int a, int b) {
+        const int e = make_edge(pc, dest(a), org[b]);
+        splice(e, lnext(a));
+        splice(e ^ 1, b);
+        return e;
+    }
+    void delete_edge(Piece& pc, int e) {
+        splice(e, prev[e]);
+        splice(e ^ 1, prev[e ^ 1]);
+        release(pc, e);
+    }
+
+    // hull edges of a piece for a parent that cuts along `axis`: walk the hull counter-clockwise once
+    void reorient(Piece& pc, int axis) const {
+        int e = pc.le, lo = pc.le, hi_in = -1;
+        int vmin = org[e], vmax = -1;
+        do {
+            const int v = dest(e);  // e arrives at v, rprev(e) leaves it along the hull
+            if (vmax < 0 || before(axis, vmax, v)) {
+                vmax = v;
+                hi_in = e;
+            }
+            const int out = rprev(e);
+            if (before(axis, v, vmin)) {
+                vmin = v;
+                lo = out;
+            }
+            e = out;
+        } while (e != pc.le);
+        pc.le = lo;
+        pc.re = sym(hi_in);
+    }
+
+    Piece leaf(int l, int r, int axis) {
+        const int n = r - l;
+        std::sort(ids.get() + l, ids.get() + r, [&](int a, int b) { return before(axis, a, b); });
+        Piece pc;
+        pc.free_head = pc.free_tail = -1;
+        for (int k = 3 * r - 1; k >= 3 * l; --k) {  // every slot of the piece starts free, lowest slot first
+            org[2 * k] = org[2 * k + 1] = -1;
+            next[2 * k] = pc.free_head;
+            if (pc.free_head < 0) pc.free_tail = 2 * k;
+            pc.free_head = 2 * k;
         }
-        const i128 ax = px[a] - px[d], ay = py[a] - py[d];
-        const i128 bx = px[b] - px[d], by = py[b] - py[d];
-        const i128 cx = px[c] - px[d], cy = py[c] - py[d];
-        const i128 a2 = ax * ax + ay * ay, b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
-        return ax * (by * c2 - b2 * cy) - ay * (bx * c2 - b2 * cx) + a2 * (bx * cy - by * cx) > 0;
+        const int s1 = ids[l], s2 = ids[l + 1];
+        const int a = make_edge(pc, s1, s2);
+        if (n == 2) {
+            pc.le = a;
+            pc.re = a ^ 1;
+            return pc;
+        }
+        const int s3 = ids[l + 2];
+        const int b = make_edge(pc, s2, s3);
+        splice(a ^ 1, b);
+        const long long o = ccw(s1, s2, s3);
+        if (o > 0) {
+            connect(pc, b, a);
+            pc.le = a;
+            pc.re = b ^ 1;
+        } else if (o < 0) {
+            const int c = connect(pc, b, a);
+            pc.le = c ^ 1;
+            pc.re = c;
+        } else {  // collinear: a chain of two edges
+            pc.le = a;
+            pc.re = b ^ 1;
+        }
+        return pc;
     }
-    // sign of orient for image points only (64-bit exact)
-    inline long long orient64(int a, int b, int c) const { return (px[b] - px[a]) * (py[c] - py[a]) - (py[b] - py[a]) * (px[c] - px[a]); }
-    inline bool right_of(int a, int b, int p) const {
-        if (a >= 3 && b >= 3) return orient64(a, b, p) < 0;
-        return orient(a, b, p) < 0;
-    }
-    std::vector<int> free_slots;  // slots of deleted triangles are reused: the live mesh stays ~2N entries (cache resident)
-    int locate(int p) {
-        int t = last;
-        for (size_t guard = 0; guard < tris.size() * 3 + 16; ++guard) {
-            bool moved = false;
-            for (int i = 0; i < 3; ++i) {
-                const int a = tris[t].v[(i + 1) % 3], b = tris[t].v[(i + 2) % 3];
-                if (right_of(a, b, p)) {
-                    t = tris[t].n[i];
-                    moved = true;
-                    break;
+
+    // `slot` numbers the thread that runs this subtree (0 = the caller's): a new thread takes the left half
+    Piece build(int l, int r, int axis, int depth, int slot) {
+        const int n = r - l;
+        if (n <= 3) return leaf(l, r, axis);
+        const int m = l + n / 2;
+        std::nth_element(ids.get() + l, ids.get() + m, ids.get() + r, [&](int a, int b) { return before(axis, a, b); });
+        Piece L, R;
+        if (depth < par_depth) {
+            const int left_slot = slot + (1 << (par_depth - depth - 1));
+            std::thread left([&] {
+                cpus->pin(left_slot);
+                L = build(l, m, axis ^ 1, depth + 1, left_slot);
+            });
+            R = build(m, r, axis ^ 1, depth + 1, slot);
+            left.join();
+        } else {
+            L = build(l, m, axis ^ 1, depth + 1, slot);
+            R = build(m, r, axis ^ 1, depth + 1, slot);
+        }
+        reorient(L, axis);
+        reorient(R, axis);
+        Piece pc;
+        // the free slots of both halves serve the merge
+        if (L.free_head < 0) {
+            pc.free_head = R.free_head;
+            pc.free_tail = R.free_tail;
+        } else {
+            pc.free_head = L.free_head;
+            pc.free_tail = L.free_tail;
+            if (R.free_head >= 0) {
+                next[L.free_tail] = R.free_head;
+                pc.free_tail = R.free_tail;
+            }
+        }
+        int ldo = L.le, ldi = L.re, rdi = R.le, rdo = R.re;
+        // lower common tangent
+        for (;;) {
+            if (left_of(org[rdi], ldi))
+                ldi = lnext(ldi);
+            else if (right_of(org[ldi], rdi))
+                rdi = rprev(rdi);
+            else
+                break;
+        }
+        int basel = connect(pc, sym(rdi), ldi);
+        if (org[ldi] == org[ldo]) ldo = sym(basel);
+        if (org[rdi] == org[rdo]) rdo = basel;
+        for (;;) {
+            int lcand = next[sym(basel)];
+            const bool lvalid0 = right_of(dest(lcand), basel);
+            if (lvalid0)
+                while (in_circle(dest(basel), org[basel], dest(lcand), dest(next[lcand]))) {
+                    const int t = next[lcand];
+                    delete_edge(pc, lcand);
+                    lcand = t;
                 }
-            }
-            if (!moved) return t;
-        }
-        return t;
-    }
-    bool insert(int p) {
-        const int t0 = locate(p);
-        for (int i = 0; i < 3; ++i)
-            if (px[tris[t0].v[i]] == px[p] && py[tris[t0].v[i]] == py[p]) return false;  // duplicate point
-        // cavity = connected set of triangles whose circumcircle strictly contains p
-        cavity.clear();
-        stack.clear();
-        edges.clear();
-        stack.push_back(t0);
-        dead[t0] = 2;
-        while (!stack.empty()) {
-            const int t = stack.back();
-            stack.pop_back();
-            cavity.push_back(t);
-            for (int i = 0; i < 3; ++i) {
-                const int nb = tris[t].n[i];
-                if (nb < 0 || dead[nb]) continue;
-                if (incircle_pos(tris[nb].v[0], tris[nb].v[1], tris[nb].v[2], p)) {
-                    dead[nb] = 2;
-                    stack.push_back(nb);
+            int rcand = prev[basel];
+            const bool rvalid0 = right_of(dest(rcand), basel);
+            if (rvalid0)
+                while (in_circle(dest(basel), org[basel], dest(rcand), dest(prev[rcand]))) {
+                    const int t = prev[rcand];
+                    delete_edge(pc, rcand);
+                    rcand = t;
                 }
-            }
+            const bool lvalid = right_of(dest(lcand), basel), rvalid = right_of(dest(rcand), basel);
+            if (!lvalid && !rvalid) break;
+            if (!lvalid || (rvalid && in_circle(dest(lcand), org[lcand], org[rcand], dest(rcand))))
+                basel = connect(pc, rcand, sym(basel));
+            else
+                basel = connect(pc, sym(basel), sym(lcand));
         }
-        for (int t : cavity)
-            for (int i = 0; i < 3; ++i) {
-                const int nb = tris[t].n[i];
-                if (nb >= 0 && dead[nb] == 2) continue;
-                Edge e;
-                e.a = tris[t].v[(i + 1) % 3];
-                e.b = tris[t].v[(i + 2) % 3];
-                e.outer = nb;
-                e.tri = -1;
-                edges.push_back(e);
-                // remember which cavity triangle the outer neighbour pointed to
-                if (nb >= 0)
-                    for (int j = 0; j < 3; ++j)
-                        if (tris[nb].n[j] == t) tris[nb].n[j] = -2 - (int)(edges.size() - 1);
-            }
-        for (int t : cavity) {
-            dead[t] = 1;
-            free_slots.push_back(t);
+        pc.le = ldo;
+        pc.re = rdo;
+        return pc;
+    }
+};
+
+int HostThreads() {
+    if (const char* e = std::getenv("MPMVS_HOST_THREADS")) return std::max(1, std::atoi(e));
+    const unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::min(16u, std::max(1u, hc));
+}
+}  // namespace
+
+namespace {
+// distinct points (the first occurrence stays): a bitmap over the bounding box, or a sort when that would be huge.
+// Returns false when the extent is beyond the exact range of the predicates.
+bool DistinctPoints(const Point* pts, size_t count, std::vector<Point>& out, bool& wide) {
+    out.clear();
+    if (count == 0) return true;
+    int x0 = pts[0].x, x1 = x0, y0 = pts[0].y, y1 = y0;
+    for (size_t i = 0; i < count; ++i) {
+        x0 = std::min(x0, pts[i].x);
+        x1 = std::max(x1, pts[i].x);
+        y0 = std::min(y0, pts[i].y);
+        y1 = std::max(y1, pts[i].y);
+    }
+    const long long bw = (long long)x1 - x0 + 1, bh = (long long)y1 - y0 + 1;
+    if (bw >= (1 << 24) || bh >= (1 << 24)) return false;  // the 128-bit in-circle determinant is exact below 2^24
+    wide = bw >= (1 << 13) || bh >= (1 << 13);
+    out.reserve(count);
+    if (bw * bh <= (1LL << 28)) {
+        std::vector<uint64_t> seen((size_t)((bw * bh + 63) / 64), 0);
+        for (size_t i = 0; i < count; ++i) {
+            const long long k = (long long)(pts[i].y - y0) * bw + (pts[i].x - x0);
+            if (seen[(size_t)(k >> 6)] >> (k & 63) & 1) continue;
+            seen[(size_t)(k >> 6)] |= 1ULL << (k & 63);
+            out.push_back(pts[i]);
         }
-        for (Edge& e : edges) {
-            Tri nt;
-            nt.v[0] = p;
-            nt.v[1] = e.a;
-            nt.v[2] = e.b;
-            nt.n[0] = e.outer;
-            nt.n[1] = nt.n[2] = -1;
-            if (!free_slots.empty()) {
-                e.tri = free_slots.back();
-                free_slots.pop_back();
-                tris[e.tri] = nt;
-                dead[e.tri] = 0;
-            } else {
-                e.tri = (int)tris.size();
-                tris.push_back(nt);
-                dead.push_back(0);
-            }
+    } else {
+        std::vector<size_t> idx(count);
+        for (size_t i = 0; i < count; ++i) idx[i] = i;
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return pts[a].x != pts[b].x ? pts[a].x < pts[b].x : pts[a].y < pts[b].y; });
+        std::vector<char> keep(count, 1);
+        for (size_t i = 1; i < count; ++i)
+            if (pts[idx[i]].x == pts[idx[i - 1]].x && pts[idx[i]].y == pts[idx[i - 1]].y) keep[idx[i]] = 0;
+        for (size_t i = 0; i < count; ++i)
+            if (keep[i]) out.push_back(pts[i]);
+    }
+    return true;
+}
+
+// A finished triangulation; triangles are listed by their lowest half-edge, in half-edge order.
+struct Triangulation {
+    std::vector<Point> pts;
+    Zipper z;
+    CpuPlacement cpus;
+    int threads = 1, chunks = 1, E = 0;
+    std::vector<size_t> first;  // first[c] = number of triangles in the half-edge chunks before c; first[chunks] = total
+
+    // the triangles whose lowest half-edge lies in [e0, e1): counted (out == nullptr) or written
+    size_t faces(int e0, int e1, Triangle* out) const {
+        size_t k = 0;
+        for (int e = e0; e < e1; ++e) {
+            const int a = z.org[e];
+            if (a < 0) continue;
+            const int e2 = z.lnext(e);
+            if (e2 < e) continue;
+            const int e3 = z.lnext(e2);
+            if (e3 < e || z.dest(e3) != a) continue;
+            const int b = z.org[e2], c = z.org[e3];
+            if (z.ccw(a, b, c) <= 0) continue;  // the outer face of a three-cornered hull
+            if (out) out[k] = Triangle(pts[(size_t)a], pts[(size_t)b], pts[(size_t)c]);
+            ++k;
         }
-        for (size_t k = 0; k < edges.size(); ++k) {
-            const Edge& e = edges[k];
-            if (e.outer >= 0)
-                for (int j = 0; j < 3; ++j)
-                    if (tris[e.outer].n[j] == -2 - (int)k) tris[e.outer].n[j] = e.tri;
-            for (const Edge& f : edges) {
-                if (f.a == e.b) tris[e.tri].n[1] = f.tri;  // across edge (b, p)
-                if (f.b == e.a) tris[e.tri].n[2] = f.tri;  // across edge (p, a)
-            }
-        }
-        last = edges.empty() ? last : edges[0].tri;
+        return k;
+    }
+    template <class F>
+    void for_chunks(F&& fn) const {
+        std::vector<std::thread> pool;
+        for (int c = 1; c < chunks; ++c)
+            pool.emplace_back([&, c] {
+                cpus.pin(c);
+                fn(c);
+            });
+        fn(0);
+        for (std::thread& t : pool) t.join();
+    }
+    int chunk_begin(int c) const { return (int)((long long)E * c / chunks); }
+
+    bool run(const Point* points, size_t count) {
+        bool wide = false;
+        if (!DistinctPoints(points, count, pts, wide)) return false;
+        const int n = (int)pts.size();
+        first.assign(2, 0);
+        if (n < 3) return true;
+        z.P = pts.data();
+        z.wide = wide;
+        z.next.reset(new int[(size_t)6 * n]);
+        z.prev.reset(new int[(size_t)6 * n]);
+        z.org.reset(new int[(size_t)6 * n]);
+        z.ids.reset(new int[(size_t)n]);
+        for (int i = 0; i < n; ++i) z.ids[i] = i;
+        threads = n >= 4096 ? HostThreads() : 1;
+        while ((2 << z.par_depth) <= threads) ++z.par_depth;
+        cpus.enter(threads);
+        z.cpus = &cpus;
+        z.build(0, n, 0, 0, 0);
+        E = 6 * n;
+        chunks = threads;
+        std::vector<size_t> counts((size_t)chunks, 0);
+        for_chunks([&](int c) { counts[(size_t)c] = faces(chunk_begin(c), chunk_begin(c + 1), nullptr); });
+        first.assign((size_t)chunks + 1, 0);
+        for (int c = 0; c < chunks; ++c) first[(size_t)c + 1] = first[(size_t)c] + counts[(size_t)c];
         return true;
+    }
+    size_t total() const { return first.back(); }
+    // all triangles into out[0 .. total())
+    void write(Triangle* out) const {
+        if (total() == 0) return;
+        for_chunks([&](int c) { faces(chunk_begin(c), chunk_begin(c + 1), out + first[(size_t)c]); });
     }
 };
 }  // namespace
 
 std::vector<Triangle> Delaunay(const Rect boundRC, const std::vector<Point>& points) {
-    std::vector<Triangle> results;
-    if (points.empty()) return results;
-    Mesh m;
-    const long long K = 1LL << 24;  // super triangle far outside any image (exactness: |coord| < 2^26)
     (void)boundRC;
-    m.px = {-K, 3 * K, -K};
-    m.py = {-K, -K, 3 * K};
-    m.px.reserve(points.size() + 3);
-    m.py.reserve(points.size() + 3);
-    m.tris.reserve(points.size() * 2 + 64);
-    m.dead.reserve(points.size() * 2 + 64);
-    Tri t0;
-    t0.v[0] = 0;
-    t0.v[1] = 1;
-    t0.v[2] = 2;
-    t0.n[0] = t0.n[1] = t0.n[2] = -1;
-    m.tris.push_back(t0);
-    m.dead.push_back(0);
-    // Insertion order: the vertices arrive sorted by 5x5 cell in row-major order,
-    // which makes every new point fall just outside the current hull and blows the
-    // Bowyer-Watson cavities up (measured: 23 triangles per insert).  A biased
-    // multi-level order -- cells on a stride-8 lattice first, then stride 4, 2, 1,
-    // row-major inside each level -- keeps cavities at ~5 triangles and walks
-    // short.  Deterministic; the triangulation itself does not depend on the order
-    // (up to cocircular ties).
-    std::vector<int> order(points.size());
-    for (size_t i = 0; i < points.size(); ++i) order[i] = (int)i;
-    auto level = [&](int i) {
-        const int cx = points[i].x / 5, cy = points[i].y / 5;
-        if (cx % 8 == 0 && cy % 8 == 0) return 0;
-        if (cx % 4 == 0 && cy % 4 == 0) return 1;
-        if (cx % 2 == 0 && cy % 2 == 0) return 2;
-        return 3;
-    };
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return level(a) < level(b); });
-    for (const Point& p : points) {
-        m.px.push_back(p.x);
-        m.py.push_back(p.y);
-    }
-    for (int i : order) m.insert(i + 3);
-    for (size_t t = 0; t < m.tris.size(); ++t) {
-        if (m.dead[t]) continue;
-        const Tri& T = m.tris[t];
-        if (T.v[0] < 3 || T.v[1] < 3 || T.v[2] < 3) continue;  // touches the super triangle
-        results.push_back(Triangle(Point((int)m.px[T.v[0]], (int)m.py[T.v[0]]), Point((int)m.px[T.v[1]], (int)m.py[T.v[1]]),
-                                   Point((int)m.px[T.v[2]], (int)m.py[T.v[2]])));
-    }
+    std::vector<Triangle> results;
+    Triangulation t;
+    if (!t.run(points.data(), points.size())) return results;
+    results.resize(t.total());
+    t.write(results.data());
     return results;
+}
+
+// the same from / into plain arrays (xy pairs in, six ints per triangle out): returns the number of triangles, writes them only
+// if they all fit into `cap`; -1 when the coordinates are out of range
+long long DelaunayXY(const int* xy, size_t count, int* tri_xy, size_t cap) {
+    static_assert(sizeof(Point) == 2 * sizeof(int) && sizeof(Triangle) == 6 * sizeof(int), "Point / Triangle are plain int tuples");
+    Triangulation t;
+    if (!t.run(reinterpret_cast<const Point*>(xy), count)) return -1;
+    if (t.total() <= cap) t.write(reinterpret_cast<Triangle*>(tri_xy));
+    return (long long)t.total();
 }
 
 // ---------------------------------------------------------------------------

@@ -82,8 +82,8 @@ def delaunay(w, h, points):
     cap = 2 * len(pts) + 8
     out = np.empty((cap, 3, 2), np.int32)
     n = lib.mpmvs_host_delaunay(w, h, pts.ctypes.data, len(pts), out.ctypes.data, cap)
-    assert n <= cap
-    return out[:n].copy()
+    assert 0 <= n <= cap
+    return out[:n]
 
 
 def build_prior(cam, planes, costs, geom_costs, geom_planar_prior, depth_min, depth_max):

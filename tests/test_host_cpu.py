@@ -110,6 +110,115 @@ def test_delaunay_grid_points_and_duplicates(hostlib):
     assert len(tris) == 2 * 9 * 7
 
 
+def _check_triangulation(pts, tris):
+    """vectorised validity check of a triangulation of integer points: counter-clockwise triangles over the given points,
+    every interior edge locally Delaunay (exact int64), triangles tile the convex hull, triangle count = 2n - 2 - hull"""
+    from scipy.spatial import ConvexHull
+    pts = np.asarray(pts, np.int64)
+    n = len(pts)
+    W = int(pts[:, 0].max()) + 1
+    lut = {int(y) * W + int(x): i for i, (x, y) in enumerate(pts.tolist())}
+    t = np.asarray(tris, np.int64)
+    ids = np.array([lut[int(k)] for k in (t[:, :, 1] * W + t[:, :, 0]).ravel()], np.int64).reshape(-1, 3)
+    P = pts[ids]                                            # T x 3 x 2
+    o = (P[:, 1, 0] - P[:, 0, 0]) * (P[:, 2, 1] - P[:, 0, 1]) - (P[:, 1, 1] - P[:, 0, 1]) * (P[:, 2, 0] - P[:, 0, 0])
+    assert (o > 0).all(), "counter-clockwise, non-degenerate"
+    hull = ConvexHull(pts.astype(float))
+    assert int(o.sum()) == int(round(2 * hull.volume)), "the triangles tile the convex hull"
+    on_hull = 0                                             # points ON the hull boundary (qhull lists corners only)
+    hv = pts[hull.vertices]
+    for a, b in zip(hv, np.roll(hv, -1, axis=0)):
+        d = b - a
+        cross = (pts[:, 0] - a[0]) * d[1] - (pts[:, 1] - a[1]) * d[0]
+        dot = (pts[:, 0] - a[0]) * d[0] + (pts[:, 1] - a[1]) * d[1]
+        on_hull += int(((cross == 0) & (dot >= 0) & (dot < d @ d)).sum())
+    assert len(t) == 2 * n - 2 - on_hull
+    assert len(np.unique(ids)) == n, "every point is used"
+    # directed edges u->v with the opposite corner w; the twin v->u belongs to the neighbour
+    u = ids[:, [0, 1, 2]].ravel()
+    v = ids[:, [1, 2, 0]].ravel()
+    w = ids[:, [2, 0, 1]].ravel()
+    key, twin = u * n + v, v * n + u
+    assert len(np.unique(key)) == len(key), "no directed edge twice (no overlapping triangles)"
+    order = np.argsort(key)
+    pos = np.searchsorted(key[order], twin)
+    pos[pos >= len(key)] = 0
+    has = key[order][pos] == twin
+    w2 = w[order][pos]
+    A, B, C, D = pts[u[has]], pts[v[has]], pts[w[has]], pts[w2[has]]
+    ax, ay = A[:, 0] - D[:, 0], A[:, 1] - D[:, 1]
+    bx, by = B[:, 0] - D[:, 0], B[:, 1] - D[:, 1]
+    cx, cy = C[:, 0] - D[:, 0], C[:, 1] - D[:, 1]
+    a2, b2, c2 = ax * ax + ay * ay, bx * bx + by * by, cx * cx + cy * cy
+    det = ax * (by * c2 - b2 * cy) - ay * (bx * c2 - b2 * cx) + a2 * (bx * cy - by * cx)
+    assert (det <= 0).all(), "an opposite corner lies strictly inside a circumcircle"
+    assert int((~has).sum()) == on_hull, "exactly the hull edges have no twin"
+
+
+def _cell_vertices(W, H, per_cell, seed):
+    """the vertex pattern of the planar prior: up to per_cell distinct pixels in every 5x5 cell, cells in raster order"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for cy in range(H // 5):
+        for cx in range(W // 5):
+            for q in sorted(rng.choice(25, per_cell, replace=False).tolist()):
+                out.append((cx * 5 + q % 5, cy * 5 + q // 5))
+    return np.array(out, np.int32)
+
+
+@pytest.mark.parametrize("W,H,per_cell", [(400, 300, 3), (480, 320, 1), (1280, 95, 2)])
+def test_delaunay_large_sets_parallel_and_serial_agree(hostlib, monkeypatch, W, H, per_cell):
+    """above 4096 points the subtrees run on their own threads: the result is a valid Delaunay triangulation of the grid-bound
+    (hence heavily cocircular) vertex pattern and identical, triangle for triangle, for every number of threads"""
+    pts = _cell_vertices(W, H, per_cell, seed=W + per_cell)
+    assert len(pts) >= 4096
+    ref = None
+    for threads in ("1", "2", "5", "8"):
+        monkeypatch.setenv("MPMVS_HOST_THREADS", threads)
+        tris = np.array(hostlib.delaunay(W, H, pts))
+        if ref is None:
+            ref = tris
+            _check_triangulation(pts, tris)
+        else:
+            assert np.array_equal(ref, tris), f"{threads} threads"
+
+
+def test_delaunay_full_lattice_parallel(hostlib, monkeypatch):
+    """every quadruple of neighbours cocircular, every row and column collinear, 8 threads"""
+    monkeypatch.setenv("MPMVS_HOST_THREADS", "8")
+    xs, ys = np.meshgrid(np.arange(0, 300, 3), np.arange(0, 180, 3))
+    pts = np.stack([xs.ravel(), ys.ravel()], -1).astype(np.int32)
+    np.random.default_rng(0).shuffle(pts)
+    _check_triangulation(pts, hostlib.delaunay(300, 180, pts))
+
+
+def test_delaunay_degenerate_inputs(hostlib):
+    assert len(hostlib.delaunay(10, 10, np.zeros((0, 2), np.int32))) == 0
+    assert len(hostlib.delaunay(10, 10, np.array([[1, 1], [5, 2]], np.int32))) == 0
+    line = np.stack([np.arange(40), 2 * np.arange(40)], -1).astype(np.int32)
+    assert len(hostlib.delaunay(100, 100, line)) == 0                                  # all collinear: no triangle
+    vertical = np.stack([np.full(30, 7), np.arange(30)], -1).astype(np.int32)
+    assert len(hostlib.delaunay(100, 100, vertical)) == 0
+    fan = np.concatenate([vertical, np.array([[20, 11]], np.int32)])                   # a collinear chain and one apex
+    tris = hostlib.delaunay(100, 100, fan)
+    assert len(tris) == 29
+    _check_triangulation(fan, tris)
+    two_lines = np.concatenate([vertical, vertical + np.array([1, 0], np.int32)])      # two adjacent collinear chains
+    _check_triangulation(two_lines, hostlib.delaunay(100, 100, two_lines))
+    dup = np.repeat(np.array([[3, 4], [9, 1], [6, 8]], np.int32), 5, axis=0)            # duplicates of three points
+    assert len(hostlib.delaunay(100, 100, dup)) == 1
+    rng = np.random.default_rng(3)
+    for n in range(3, 40):                                                             # every small piece size of the recursion
+        pts = np.unique(rng.integers(0, 12, size=(n, 2)), axis=0).astype(np.int32)
+        if len(pts) < 3:
+            continue
+        tris = hostlib.delaunay(12, 12, pts)
+        if len(tris):
+            _check_triangulation(pts, tris)
+    far = np.array([[0, 0], [9000, 10], [20, 8999], [8000, 8000], [4000, 4100], [4100, 4000], [100, 5000]], np.int32)
+    _check_triangulation(far, hostlib.delaunay(9001, 9000, far))                       # 128-bit in-circle path
+
+
 def test_triangulate_vertices(hostlib):
     costs = np.full((23, 31), 1.5, np.float32)
     costs[2, 3] = 0.05      # cell (0,0) -> vertex (3,2)
