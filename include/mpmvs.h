@@ -163,8 +163,7 @@ int mpmvs_export_depth_device(mpmvs_ctx* ctx, float* d_out);
  * planes against every source view; out is [num_images-1][H][W] */
 int mpmvs_eval_ncc(mpmvs_ctx* ctx, const mpmvs_params* params, const void* planes_cam4, int scale, void* out);
 /* the same for nh planes per pixel (planes_cam4 = [nh][H][W] float4, out = [nh][num_images-1][H][W]) with a choice of
- * the lane mapping: 0 = one thread per pixel; 1 / 2 = groups of 4 lanes per pixel sharing the evaluations of the pixel,
- * compiled for 4 / 3 waves per SIMD; 3 / 4 = groups of 8 lanes.  All mappings give identical bits.  *kernel_ms
+ * the lane mapping: only 0 (one thread per pixel) exists; the cooperative lane-group mappings tried in round 2 were removed.  *kernel_ms
  * (may be NULL) receives the device time of the kernel (HIP events). */
 int mpmvs_eval_ncc_multi(mpmvs_ctx* ctx, const mpmvs_params* params, const void* planes_cam4, int nh, int scale, int mapping,
                          void* out, float* kernel_ms);

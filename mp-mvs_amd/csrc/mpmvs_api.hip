@@ -32,7 +32,6 @@
 #include "pm_fusion.hpp"
 #include "pm_sky.hpp"
 #include "pm_kernels.hpp"
-#include "pm_coop.hpp"
 #include "pm_prior.hpp"
 
 using namespace pm;
@@ -630,19 +629,34 @@ static dim3 checker_grid(const mpmvs_ctx* c, const LaunchArgs& a) {
 // The per-view arrays of the update kernel (8 x V candidate costs and four V-vectors, in scratch) are sized by a template
 // bound on the number of source views: buckets of 8 keep that scratch and the register pressure around it proportional to the
 // Problem (the shipped configuration allows 20 views, reference config/config.yaml:19; the hard limit is 32, ref .cu:500).
-template <bool GEOM, bool PRIOR, bool U8>
-static void launch_update2(mpmvs_ctx* c, const LaunchArgs& a) {
+template <bool GEOM, bool PRIOR, bool U8, int SCALE>
+static void launch_update3(mpmvs_ctx* c, const LaunchArgs& a) {
     const dim3 grid = checker_grid<U8>(c, a);
-    const size_t lds = ncc_lds_bytes(kChkBlockW<U8>, kChkBlockH<U8>, a.scale);
+    // MPMVS_LDS_PAD_KB (measurement aid): extra dynamic LDS per block, to hold the update kernel at fewer blocks per CU
+    static const size_t pad = std::getenv("MPMVS_LDS_PAD_KB") ? (size_t)std::atoi(std::getenv("MPMVS_LDS_PAD_KB")) * 1024 : 0;
+    const size_t lds = ncc_lds_bytes(kChkBlockW<U8>, kChkBlockH<U8>, SCALE) + pad;
     const int V = c->hP.V;
     if (V <= 8)
-        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 8, U8>), grid, dim3(256), lds, c->stream, c->dP, c->S, a);
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 8, U8, SCALE>), grid, dim3(256), lds, c->stream, c->dP, c->S, a);
     else if (V <= 16)
-        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 16, U8>), grid, dim3(256), lds, c->stream, c->dP, c->S, a);
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 16, U8, SCALE>), grid, dim3(256), lds, c->stream, c->dP, c->S, a);
     else if (V <= 24)
-        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 24, U8>), grid, dim3(256), lds, c->stream, c->dP, c->S, a);
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 24, U8, SCALE>), grid, dim3(256), lds, c->stream, c->dP, c->S, a);
     else
-        hipLaunchKernelGGL((k_update<GEOM, PRIOR, kMaxViews, U8>), grid, dim3(256), lds, c->stream, c->dP, c->S, a);
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, kMaxViews, U8, SCALE>), grid, dim3(256), lds, c->stream, c->dP, c->S, a);
+}
+// The window scale is a template parameter of the NCC kernels (pm_device.hpp, Win).  The photometric update exists at the
+// scales 0..2 of the multi-scale schedule; the geometric and the prior update run at scale 0 only, as Run() does (ref
+// .cu:1188-1254: the scale loop belongs to the photometric branch).
+template <bool GEOM, bool PRIOR, bool U8>
+static void launch_update2(mpmvs_ctx* c, const LaunchArgs& a) {
+    if constexpr (GEOM || PRIOR) {
+        launch_update3<GEOM, PRIOR, U8, 0>(c, a);
+    } else {
+        if (a.scale == 0) launch_update3<false, false, U8, 0>(c, a);
+        if (a.scale == 1) launch_update3<false, false, U8, 1>(c, a);
+        if (a.scale == 2) launch_update3<false, false, U8, 2>(c, a);
+    }
 }
 template <bool GEOM, bool PRIOR>
 static void launch_update(mpmvs_ctx* c, const LaunchArgs& a) {
@@ -654,6 +668,8 @@ static void launch_update(mpmvs_ctx* c, const LaunchArgs& a) {
 
 static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int kind, int iter, int scale, uint32_t launch) {
     if (scale < 0 || scale > 2) return fail(c, -3, "scale must be 0..2");
+    if ((kind == MPMVS_KIND_BLACK || kind == MPMVS_KIND_RED) && scale != 0 && (p->geom_consistency || p->planar_prior))
+        return fail(c, -3, "geometric / planar-prior updates run at scale 0 only (as Run() does)");
     LaunchArgs a;
     a.seed = seed;
     a.launch = launch;
@@ -682,12 +698,18 @@ static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int 
         case MPMVS_KIND_INIT: {
             const size_t lds = ncc_lds_bytes(16, 16, a.scale);
             const int V = c->hP.V;
-#define PM_LAUNCH_INIT(MV)                                                                                                  \
+#define PM_LAUNCH_INIT2(MV, SC)                                                                                             \
     do {                                                                                                                    \
         if (c->all_u8)                                                                                                      \
-            hipLaunchKernelGGL((k_init<MV, true>), grid_dense, blk, lds, c->stream, c->dP, c->S, a);                        \
+            hipLaunchKernelGGL((k_init<MV, true, SC>), grid_dense, blk, lds, c->stream, c->dP, c->S, a);                    \
         else                                                                                                                \
-            hipLaunchKernelGGL((k_init<MV, false>), grid_dense, blk, lds, c->stream, c->dP, c->S, a);                       \
+            hipLaunchKernelGGL((k_init<MV, false, SC>), grid_dense, blk, lds, c->stream, c->dP, c->S, a);                   \
+    } while (0)
+#define PM_LAUNCH_INIT(MV)                  \
+    do {                                    \
+        if (a.scale == 0) PM_LAUNCH_INIT2(MV, 0); \
+        if (a.scale == 1) PM_LAUNCH_INIT2(MV, 1); \
+        if (a.scale == 2) PM_LAUNCH_INIT2(MV, 2); \
     } while (0)
             if (V <= 8)
                 PM_LAUNCH_INIT(8);
@@ -697,6 +719,7 @@ static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int 
                 PM_LAUNCH_INIT(24);
             else
                 PM_LAUNCH_INIT(kMaxViews);
+#undef PM_LAUNCH_INIT2
 #undef PM_LAUNCH_INIT
             break;
         }
@@ -813,15 +836,15 @@ int mpmvs_export_depth_device(mpmvs_ctx* c, float* d_out) {
     return 0;
 }
 
-// mapping: 0 = one thread per pixel (k_eval_ncc), 1/2 = cooperative groups of 4 lanes per pixel compiled for 4 / 3 waves
-// per SIMD, 3/4 = groups of 8 lanes, 4 / 3 waves per SIMD (pm_coop.hpp)
+// mapping: 0 = one thread per pixel (k_eval_ncc); the cooperative lane-group mappings 1..4 of round 2 were measured, not
+// adopted and removed again
 static int eval_ncc_impl(mpmvs_ctx* c, const mpmvs_params* p, const void* planes_cam4, int nh, int scale, int mapping, void* out, float* kernel_ms) {
     if (!c || !p) return -1;
     HIPCHK(c, enter_device(c->device));
     int rc = check_ready(c, p);
     if (rc) return rc;
     if (scale < 0 || scale > 2) return fail(c, -3, "scale must be 0..2");
-    if (nh < 1 || mapping < 0 || mapping > 4) return fail(c, -3, "bad probe arguments");
+    if (nh < 1 || mapping != 0) return fail(c, -3, "bad probe arguments (only mapping 0 exists)");
     const size_t wh = (size_t)c->W * c->H;
     const int V = c->hP.V;
     DevBuf d_pl, d_out;
@@ -834,37 +857,26 @@ static int eval_ncc_impl(mpmvs_ctx* c, const mpmvs_params* p, const void* planes
     a.two_sc = (2.0f * p->sigma_color) * p->sigma_color;
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     HIPCHK(c, hipEventRecord(e0, c->stream));
-    const int radius = 5 * (2 << scale) / 2;
-    if (mapping == 0) {
+    {
         const dim3 grid((c->W + 15) / 16, (c->H + 15) / 16);
         const size_t lds = ncc_lds_bytes(16, 16, scale);
+#define PM_LAUNCH_EVAL(MV, U, SC) hipLaunchKernelGGL((k_eval_ncc<MV, U, SC>), grid, dim3(256), lds, c->stream, c->dP, d_pl.as<float4>(), nh, d_out.as<float>(), a)
+#define PM_LAUNCH_EVAL_SC(MV, U)            \
+    do {                                    \
+        if (scale == 0) PM_LAUNCH_EVAL(MV, U, 0); \
+        if (scale == 1) PM_LAUNCH_EVAL(MV, U, 1); \
+        if (scale == 2) PM_LAUNCH_EVAL(MV, U, 2); \
+    } while (0)
         if (V <= 8 && c->all_u8)
-            hipLaunchKernelGGL((k_eval_ncc<8, true>), grid, dim3(256), lds, c->stream, c->dP, d_pl.as<float4>(), nh, d_out.as<float>(), a);
+            PM_LAUNCH_EVAL_SC(8, true);
         else if (V <= 8)
-            hipLaunchKernelGGL((k_eval_ncc<8, false>), grid, dim3(256), lds, c->stream, c->dP, d_pl.as<float4>(), nh, d_out.as<float>(), a);
+            PM_LAUNCH_EVAL_SC(8, false);
         else if (c->all_u8)
-            hipLaunchKernelGGL((k_eval_ncc<kMaxViews, true>), grid, dim3(256), lds, c->stream, c->dP, d_pl.as<float4>(), nh, d_out.as<float>(), a);
+            PM_LAUNCH_EVAL_SC(kMaxViews, true);
         else
-            hipLaunchKernelGGL((k_eval_ncc<kMaxViews, false>), grid, dim3(256), lds, c->stream, c->dP, d_pl.as<float4>(), nh, d_out.as<float>(), a);
-    } else {
-        const int G = mapping <= 2 ? 4 : 8, pix = 256 / G, bh = pix / 8;
-        const dim3 grid((c->W + 7) / 8, (c->H + bh - 1) / bh);
-        const int fixed = G == 4 ? kCoopFixedFloats<4> : kCoopFixedFloats<8>;
-        const size_t lds = (size_t)(fixed + (use_ref_tile(scale, 8, bh) ? (8 + 2 * radius) * (bh + 2 * radius) : 0)) * sizeof(float);
-#define PM_LAUNCH_COOP(U8, G_, WV) \
-    hipLaunchKernelGGL((k_eval_ncc_coop<U8, G_, WV>), grid, dim3(256), lds, c->stream, c->dP, d_pl.as<float4>(), nh, d_out.as<float>(), a)
-        if (c->all_u8) {
-            if (mapping == 1) PM_LAUNCH_COOP(true, 4, 4);
-            if (mapping == 2) PM_LAUNCH_COOP(true, 4, 3);
-            if (mapping == 3) PM_LAUNCH_COOP(true, 8, 4);
-            if (mapping == 4) PM_LAUNCH_COOP(true, 8, 3);
-        } else {
-            if (mapping == 1) PM_LAUNCH_COOP(false, 4, 4);
-            if (mapping == 2) PM_LAUNCH_COOP(false, 4, 3);
-            if (mapping == 3) PM_LAUNCH_COOP(false, 8, 4);
-            if (mapping == 4) PM_LAUNCH_COOP(false, 8, 3);
-        }
-#undef PM_LAUNCH_COOP
+            PM_LAUNCH_EVAL_SC(kMaxViews, false);
+#undef PM_LAUNCH_EVAL_SC
+#undef PM_LAUNCH_EVAL
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(e1, c->stream));

@@ -303,22 +303,36 @@ PM_DEV float4 perturbed_normal(const ProblemDev& P, int px, int py, const float4
 // reference-image terms of :363-395).  The reference recomputes them for each of
 // the 14*V evaluations of a pixel; here they are computed once per pixel and
 // launch and parked in LDS:
-//   * the block's reference-image tile + halo is staged once into LDS
-//     (coalesced rows, read back as the 36 window taps of every pixel),
-//   * the 36 bilateral weights w and products w*r of a pixel live in a
-//     per-thread LDS column of 18 float4 ([tap pair][thread], one conflict-free
-//     ds_read_b128 per tap pair), leaving the VGPRs to the gather pipeline of
-//     the NCC loop.  (The kernels are register-limited to 2 blocks per CU, so
-//     the 72 KB per block cost no occupancy.)
+//   * the block's reference-image tile + halo is staged once into LDS (coalesced rows, read back as the 36 window taps of
+//     every pixel) as long as it leaves room for two blocks per CU;
+//   * the 36 bilateral weights w and products w*r of a pixel live in a per-thread LDS column of 18 float4 ([tap pair][thread],
+//     one conflict-free ds_read_b128 per tap pair), leaving the VGPRs to the gather pipeline of the NCC loop.
 // LDS layout (one array): [18 * kBlockThreads float4][tile floats].
+// Round 2 tried 4-byte records (w only, w*r recomputed from the tile in every evaluation) so that three blocks fit a CU: the
+// NCC core gains ~5 % from the third wave per SIMD but pays 4 % for the extra LDS reads and products, and the update kernel
+// squeezed into 168 registers loses more than that.
 // ---------------------------------------------------------------------------
 constexpr int kBlockThreads = 256;
+extern __shared__ float pm_lds[];  // dynamic LDS of the NCC kernels
+constexpr int kLdsWeightFloats = 2 * 36 * kBlockThreads;
 
 struct RefWin {
     // this thread's LDS column, one float4 per pair of vertically adjacent taps
     // (b = 2j, 2j+1 of window column a): (w_even, w_odd, w*r_even, w*r_odd)
     const float4* lw;  // lw[(a * 3 + j) * kBlockThreads]
     float inv_w, mean_r, var_r;
+};
+
+// Window geometry of a launch: the scale is a template parameter of the NCC kernels, so step and radius are constants.
+// The reference tile (block + halo of the window radius) is staged in LDS only while two blocks still fit a CU's 160 KB next
+// to their 72 KB of weight records, i.e. up to 2048 floats.  A larger tile would halve the occupancy of the whole kernel for
+// the sake of its prologue (measured 5.96 vs 3.9 ms per launch at scale 2), so the window is then read from the L2-resident
+// padded image instead.  With the 8 x 64 pixel blocks of the fp16 texture format that is the case from scale 1 on (28 x 84
+// floats), with the 16 x 32 blocks of the fp32 format and the 16 x 16 dense blocks from scale 2 on.
+template <int SCALE, int BW, int BH>
+struct Win {
+    static constexpr int step = 2 << SCALE, radius = 5 * step / 2, pitch = BW + 2 * radius, rows = BH + 2 * radius;
+    static constexpr bool tile_in_lds = pitch * rows <= 2048;
 };
 
 // cooperative load of the tile [x0-radius, x0+BW+radius) x [y0-radius, y0+BH+radius)
@@ -336,12 +350,12 @@ PM_DEV void load_ref_tile(const ProblemDev& P, float* tile, int x0, int y0, int 
     }
 }
 
-// weights of one pixel -> LDS column `lw`.  `ctr` points at the pixel in a reference
-// image with pitch `tpitch` whose window taps are all addressable: the block's LDS
-// tile, or (when the tile would not leave room for two blocks per CU) the
-// apron-padded image in global memory.
-PM_DEV void ref_window(float4* lw, const float* ctr, int tpitch, int step, int radius, float two_ss, float two_sc, RefWin& rw) {
-    const float rc = ctr[0];
+// weights of one pixel -> LDS column `lw`.  tap(dx, dy) reads the reference image at the pixel + (dx, dy): from the block's
+// LDS tile, or from the apron-padded image in global memory (see Win).
+template <int SCALE, class TAP>
+PM_DEV void ref_window(float4* lw, TAP tap, float two_ss, float two_sc, RefWin& rw) {
+    constexpr int step = 2 << SCALE, radius = 5 * step / 2;
+    const float rc = tap(0, 0);
     float sw = 0.0f, swr = 0.0f, swrr = 0.0f;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
@@ -350,7 +364,7 @@ PM_DEV void ref_window(float4* lw, const float* ctr, int tpitch, int step, int r
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
             const int dx = a * step - radius, dy = b * step - radius;
-            const float r = ctr[dy * tpitch + dx];
+            const float r = tap(dx, dy);
             const float sd = __builtin_sqrtf((float)dx * (float)dx + (float)dy * (float)dy);
             const float e = (-sd) / two_ss - __builtin_fabsf(r - rc) / two_sc;
             const float w = d_exp(e);
@@ -372,6 +386,25 @@ PM_DEV void ref_window(float4* lw, const float* ctr, int tpitch, int step, int r
     rw.mean_r = swr * rw.inv_w;
     const float mrr = swrr * rw.inv_w;
     rw.var_r = __builtin_fmaf(-rw.mean_r, rw.mean_r, mrr);
+}
+
+// stages the block's reference tile if it is to live in LDS and fills the pixel's weight column
+template <int SCALE, int BW, int BH>
+PM_DEV void ref_window_of_pixel(const ProblemDev& P, int x, int y, int x0, int y0, bool valid, float two_ss, float two_sc, RefWin& rw) {
+    typedef Win<SCALE, BW, BH> Wn;
+    float4* lw = (float4*)pm_lds + threadIdx.x;
+    if constexpr (Wn::tile_in_lds) {
+        load_ref_tile(P, pm_lds + kLdsWeightFloats, x0, y0, BW, BH, Wn::radius);
+        __syncthreads();
+        if (!valid) return;
+        const int ctr = kLdsWeightFloats + (y - y0 + Wn::radius) * Wn::pitch + (x - x0 + Wn::radius);
+        ref_window<SCALE>(lw, [&](int dx, int dy) { return pm_lds[ctr + dy * Wn::pitch + dx]; }, two_ss, two_sc, rw);
+    } else {
+        if (!valid) return;
+        const float* ctr = P.ref_img + (long)y * P.ref_pitch + x;
+        const int pitch = P.ref_pitch;
+        ref_window<SCALE>(lw, [&](int dx, int dy) { return ctr[dy * pitch + dx]; }, two_ss, two_sc, rw);
+    }
 }
 
 // PM_PACKED=1 writes the tap-pair arithmetic on float2 vectors (v_pk_fma/mul_f32)
@@ -407,27 +440,13 @@ PM_DEV float ubyte_to_float(uint32_t q) {
     return f;
 }
 
-// Texture handle of the cooperative kernels (pm_coop.hpp): ONE wave-uniform buffer resource spans the textures of all
-// source views (they live in one allocation); the view a lane samples is a per-lane byte offset `base` into it, and
-// pitch / clamp limits are per-lane values too.
-struct LaneTex {
-    __amdgpu_buffer_rsrc_t rsrc;
-    int pitch;  // texels per row (= w)
-    float wm1, hm1;
-    int base;   // byte offset of the view's texture
-};
-
 // byte offset of texel (ix, iy), 2^SHIFT bytes per texel
 // PM_DBG_ADDRMASK (measurement builds only, results are wrong): all gathers of a wave fall into a few cache lines, which
 // takes the texture path (TA / L1 / TD) out of the picture while the instruction stream stays the same
 template <int SHIFT, class TEX>
 PM_DEV int tex_byte_offset(const TEX& t, int iy, int ix) {
     const unsigned idx = __umul24((unsigned)iy, (unsigned)t.pitch) + (unsigned)ix;
-    unsigned off;
-    if constexpr (__is_same(TEX, LaneTex))
-        off = (idx << SHIFT) + (unsigned)t.base;  // v_lshl_add_u32
-    else
-        off = idx << SHIFT;
+    unsigned off = idx << SHIFT;
 #ifdef PM_DBG_ADDRMASK
     off &= (unsigned)(PM_DBG_ADDRMASK);
 #endif
@@ -513,10 +532,8 @@ struct BilinearTap<false> {
         ax = __builtin_amdgcn_fractf(cx);  // v_fract_f32: x - floor(x), kept below 1
         ay = __builtin_amdgcn_fractf(cy);
 #if !defined(PM_NO_IDXEN) && !defined(PM_DBG_NOLOAD) && !defined(PM_DBG_ADDRMASK)
-        if constexpr (!__is_same(TEX, LaneTex)) {
-            q = pm_struct_load_f128(t.irsrc, (int)(__umul24((unsigned)floor_to_int(cy), (unsigned)t.pitch) + (unsigned)floor_to_int(cx)), 0, 0, 0);
-            return;
-        }
+        q = pm_struct_load_f128(t.irsrc, (int)(__umul24((unsigned)floor_to_int(cy), (unsigned)t.pitch) + (unsigned)floor_to_int(cx)), 0, 0, 0);
+        return;
 #endif
         const int off = tex_byte_offset<4>(t, floor_to_int(cy), floor_to_int(cx));
 #ifdef PM_DBG_NOLOAD  // measurement builds only (results are wrong): the instruction stream without its gathers
@@ -528,7 +545,11 @@ struct BilinearTap<false> {
     PM_DEV float value() const {
         const float top = __builtin_fmaf(ax, q.y, q.x);
         const float bot = __builtin_fmaf(ax, q.w, q.z);
+#ifdef PM_EXP_INTERP3
+        return __builtin_fmaf(ay, bot, top);
+#else
         return __builtin_fmaf(ay, bot - top, top);
+#endif
     }
 };
 template <>
@@ -542,10 +563,8 @@ struct BilinearTap<true> {
         ax = __builtin_amdgcn_fractf(cx);
         ay = __builtin_amdgcn_fractf(cy);
 #if !defined(PM_NO_IDXEN) && !defined(PM_DBG_NOLOAD) && !defined(PM_DBG_ADDRMASK)
-        if constexpr (!__is_same(TEX, LaneTex)) {
-            q = pm_struct_load_b64(t.irsrc, (int)(__umul24((unsigned)floor_to_int(cy), (unsigned)t.pitch) + (unsigned)floor_to_int(cx)), 0, 0, 0);
-            return;
-        }
+        q = pm_struct_load_b64(t.irsrc, (int)(__umul24((unsigned)floor_to_int(cy), (unsigned)t.pitch) + (unsigned)floor_to_int(cx)), 0, 0, 0);
+        return;
 #endif
         const int off = tex_byte_offset<3>(t, floor_to_int(cy), floor_to_int(cx));
 #ifdef PM_DBG_NOLOAD  // measurement builds only (results are wrong): the instruction stream without its gathers
@@ -560,7 +579,11 @@ struct BilinearTap<true> {
         float top, bot;
         asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(top) : "v"(ax), "v"(q.y), "v"(q.x));
         asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[0,1,1]" : "=v"(bot) : "v"(ax), "v"(q.y), "v"(q.x));
+#ifdef PM_EXP_INTERP3
+        return __builtin_fmaf(ay, bot, top);
+#else
         return __builtin_fmaf(ay, bot - top, top);
+#endif
     }
 };
 
@@ -575,9 +598,10 @@ PM_DEV void plane_to_m(const ProblemDev& P, const float4 pl, float& m0, float& m
 // ref .cu:325-414 ComputeBilateralNCC for one (hypothesis, source view), given the homography H = A - b m^T of the
 // pair, the texture handle of the view (wave-uniform SrcTex / SrcTex8, or per-lane LaneTex) and the LDS weight records of
 // the pixel (rw.lw[rec * LWSTRIDE]).
-template <bool U8, int LWSTRIDE, class TEX>
+template <bool U8, int LWSTRIDE, int SCALE, class TEX>
 PM_DEV float ncc_core(const TEX& tex, float wf, float hf, float H0, float H1, float H2, float H3, float H4, float H5, float H6, float H7, float H8,
-                      const RefWin& rw, int px, int py, int step, int radius) {
+                      const RefWin& rw, int px, int py) {
+    constexpr int step = 2 << SCALE, radius = 5 * step / 2;
     const float fpx = (float)px, fpy = (float)py;
     {
         const float X = __builtin_fmaf(H1, fpy, __builtin_fmaf(H0, fpx, H2));
@@ -624,6 +648,21 @@ PM_DEV float ncc_core(const TEX& tex, float wf, float hf, float H0, float H1, fl
         }
     };
     // phase 2: interpolate; even/odd taps accumulate in the two halves of packed registers
+#ifdef PM_EXP_GLOBALACC
+    f32x2 A1 = {0.0f, 0.0f}, A2 = {0.0f, 0.0f}, A3 = {0.0f, 0.0f};
+    auto consume_column = [&](const float4 (&wq)[3], const BilinearTap<U8>(&tap)[6]) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const f32x2 sv = {tap[2 * j].value(), tap[2 * j + 1].value()};
+            const f32x2 w2 = {wq[j].x, wq[j].y}, wr2 = {wq[j].z, wq[j].w};
+            const f32x2 ws = w2 * sv;
+            A1 = __builtin_elementwise_fma(w2, sv, A1);
+            A2 = __builtin_elementwise_fma(ws, sv, A2);
+            A3 = __builtin_elementwise_fma(wr2, sv, A3);
+        }
+        asm volatile("" : "+v"(A3));
+    };
+#else
     auto consume_column = [&](const float4 (&wq)[3], const BilinearTap<U8>(&tap)[6]) {
         f32x2 A1 = {0.0f, 0.0f}, A2 = {0.0f, 0.0f}, A3 = {0.0f, 0.0f};
 #pragma unroll
@@ -643,6 +682,7 @@ PM_DEV float ncc_core(const TEX& tex, float wf, float hf, float H0, float H1, fl
         // the weight records from LDS there.  Pin it to the column it belongs to.
         asm volatile("" : "+v"(T3));
     };
+#endif
 #else
     auto issue_column = [&](int a, BilinearTap<U8>(&tap)[6]) {
         const float tx = (float)(px + a * step - radius);
@@ -709,6 +749,11 @@ PM_DEV float ncc_core(const TEX& tex, float wf, float hf, float H0, float H1, fl
         }
         consume_column(wB, tapB);
     }
+#if PM_PACKED && defined(PM_EXP_GLOBALACC)
+    T1 = A1.x + A1.y;
+    T2 = A2.x + A2.y;
+    T3 = A3.x + A3.y;
+#endif
     if (rcp_sum_not_finite(racc)) return 2.0f;  // no usable warp (plane through the camera centre)
     const float ms = T1 * rw.inv_w, mss = T2 * rw.inv_w, mrs = T3 * rw.inv_w;
     const float var_s = __builtin_fmaf(-ms, ms, mss);
@@ -722,8 +767,8 @@ PM_DEV float ncc_core(const TEX& tex, float wf, float hf, float H0, float H1, fl
 }
 
 // one-thread-per-pixel kernels: wave-uniform source view (constants through the scalar cache)
-template <bool U8>
-PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int step, int radius, float m0, float m1, float m2) {
+template <bool U8, int SCALE>
+PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, float m0, float m1, float m2) {
     const float H0 = __builtin_fmaf(-vw.b[0], m0, vw.A[0]);
     const float H1 = __builtin_fmaf(-vw.b[0], m1, vw.A[1]);
     const float H2 = __builtin_fmaf(-vw.b[0], m2, vw.A[2]);
@@ -739,7 +784,7 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, int s
         else
             return make_src_tex(vw);
     }();
-    return ncc_core<U8, kBlockThreads>(tex, vw.wf, vw.hf, H0, H1, H2, H3, H4, H5, H6, H7, H8, rw, px, py, step, radius);
+    return ncc_core<U8, kBlockThreads, SCALE>(tex, vw.wf, vw.hf, H0, H1, H2, H3, H4, H5, H6, H7, H8, rw, px, py);
 }
 
 // ---------------------------------------------------------------------------

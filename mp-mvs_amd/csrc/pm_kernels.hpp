@@ -10,12 +10,17 @@
 
 #include "pm_device.hpp"
 
-// minimum waves per SIMD the hot kernels are compiled for (caps the VGPR budget).
-// Measured per update launch, cfg 1, u8 textures: 2 waves (256 VGPR, no hot-loop
-// spills) 4.9 ms; 3 waves (168 VGPR, scratch spills inside the tap loop) 7.2 ms.
-#ifndef PM_WAVES_PER_SIMD
-#define PM_WAVES_PER_SIMD 2
+// waves per SIMD the NCC kernels are compiled for (2: the 72 KB of LDS weight records per block allow no more, and the update
+// kernel squeezed into the 168 registers of 3 waves loses more than the third wave gains; PM_WAVES_U8 / PM_WAVES_F32 override
+// for measurement builds)
+#ifndef PM_WAVES_U8
+#define PM_WAVES_U8 2
 #endif
+#ifndef PM_WAVES_F32
+#define PM_WAVES_F32 2
+#endif
+template <bool U8>
+constexpr int kWavesPerSimd = U8 ? PM_WAVES_U8 : PM_WAVES_F32;
 
 namespace pm {
 
@@ -109,53 +114,27 @@ PM_DEV bool dense_pixel(const ProblemDev& P, int& x, int& y) {
     return dense_pixel(P, x, y, x0, y0);
 }
 
-// dynamic LDS of the NCC kernels: 18 float4 weight records per thread + the reference tile
-extern __shared__ float pm_lds[];
-constexpr int kLdsWeightFloats = 2 * 36 * kBlockThreads;
-// The reference tile (block + halo of the window radius) is staged in LDS only while two blocks still fit a CU's 160 KB
-// next to their 72 KB of weight records, i.e. up to 2048 floats.  A larger tile would halve the occupancy of the whole
-// kernel for the sake of its prologue (measured 5.96 vs 3.9 ms per launch at scale 2), so the window is then read from the
-// L2-resident padded image instead.  With the 8 x 64 pixel blocks of the fp16 texture format that is the case from scale 1
-// on (28 x 84 floats), with the 16 x 32 blocks of the fp32 format and the 16 x 16 dense blocks from scale 2 on.
-__host__ __device__ inline bool use_ref_tile(int scale, int bw, int bh) {
-    const int radius = 5 * (2 << scale) / 2;
-    return (bw + 2 * radius) * (bh + 2 * radius) <= 2048;
-}
+// dynamic LDS of the NCC kernels (pm_lds, pm_device.hpp): 18 float4 weight records per thread + the reference tile if it fits
 inline size_t ncc_lds_bytes(int bw, int bh, int scale) {
     const int radius = 5 * (2 << scale) / 2;
-    const int tile = use_ref_tile(scale, bw, bh) ? (bw + 2 * radius) * (bh + 2 * radius) : 0;
-    return (size_t)(kLdsWeightFloats + tile) * sizeof(float);
-}
-// pointer to pixel (x, y) with all its window taps addressable, and its pitch
-PM_DEV const float* ref_center(const ProblemDev& P, float* tile, int x, int y, int x0, int y0, int bw, int bh, int radius, int scale, int& pitch) {
-    if (use_ref_tile(scale, bw, bh)) {
-        load_ref_tile(P, tile, x0, y0, bw, bh, radius);
-        __syncthreads();
-        pitch = bw + 2 * radius;
-        return tile + (y - y0 + radius) * pitch + (x - x0 + radius);
-    }
-    pitch = P.ref_pitch;
-    const int cx = x < P.W ? x : P.W - 1, cy = y < P.H ? y : P.H - 1;  // threads outside the image never use it
-    return P.ref_img + (long)cy * P.ref_pitch + cx;
+    const int tile = (bw + 2 * radius) * (bh + 2 * radius);
+    return (size_t)(kLdsWeightFloats + (tile <= 2048 ? tile : 0)) * sizeof(float);
 }
 
 // ---------------------------------------------------------------------------
 // InitializeScore, ref .cu:536-573 (+ :497-534)
 // ---------------------------------------------------------------------------
-template <int MAXV, bool U8>
-__global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_init(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
+template <int MAXV, bool U8, int SCALE>
+__global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_init(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
     const ProblemDev& P = *Pp;
     int x, y, x0, y0;
     const bool valid = dense_pixel(P, x, y, x0, y0);
-    const int step = 2 << a.scale, radius = 5 * step / 2;
-    int tpitch;
-    const float* ctr = ref_center(P, pm_lds + kLdsWeightFloats, x, y, x0, y0, 16, 16, radius, a.scale, tpitch);
+    RefWin rw;
+    ref_window_of_pixel<SCALE, 16, 16>(P, x, y, x0, y0, valid, a.two_ss, a.two_sc, rw);
     if (!valid) return;
     const int idx = y * P.W + x;
     const int V = P.V;
     Rng g = rng_make(a.seed, (uint32_t)idx, a.launch);
-    RefWin rw;
-    ref_window((float4*)pm_lds + threadIdx.x, ctr, tpitch, step, radius, a.two_ss, a.two_sc, rw);
 
     float4 pl;
     if (a.init_random) {
@@ -185,7 +164,7 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_init(const ProblemDe
     plane_to_m(P, pl, m0, m1, m2);
     int n_valid = 0;
     for (int v = 0; v < V; ++v) {
-        const float c = ncc_cost<U8>(P.views[v], rw, x, y, step, radius, m0, m1, m2);
+        const float c = ncc_cost<U8, SCALE>(P.views[v], rw, x, y, m0, m1, m2);
         cv[v] = c;
         sorted[v] = c;
         if (c < 2.0f) n_valid++;
@@ -215,7 +194,7 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_init(const ProblemDe
 // around the evaluations (fp32 texels with the planar prior, or with the geometric term above 16 views).  Measured per variant
 // (gpurun_out/r2l): parking costs the non-spilling variants 1-4 %, and gains the spilling ones 3-6 %.
 #ifndef PM_PARK_WHEN
-#define PM_PARK_WHEN (!U8 && (PRIOR || (GEOM && MAXV > 16)))
+#define PM_PARK_WHEN (kWavesPerSimd<U8> >= 3 || (!U8 && (PRIOR || (GEOM && MAXV > 16))))
 #endif
 // A private array that has to live in private MEMORY (plain loads and stores, scheduled like any others) instead of being
 // promoted to registers: its address is shown to an empty asm statement.
@@ -248,10 +227,11 @@ PM_DEV float prior_term(float depth_diff, float angle_cos, float two_ds2, float 
 // BlackPixelUpdate / RedPixelUpdate = CheckerboardPropagation +
 // PlaneHypothesisRefinement, ref .cu:724-998 and :642-722
 // ---------------------------------------------------------------------------
-template <bool GEOM, bool PRIOR, int MAXV, bool U8>
-__global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
+template <bool GEOM, bool PRIOR, int MAXV, bool U8, int SCALE>
+__global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
     const ProblemDev& P = *Pp;
     constexpr bool kGeomCall = MAXV > 8;  // see geom_cost_view
+    constexpr bool kPriorCall = MAXV > 8 || kWavesPerSimd<U8> >= 3;
 #ifdef PM_PARK_ALL
     constexpr bool kPark = true;
 #else
@@ -259,18 +239,16 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
 #endif
     int x, y, x0, y0;
     const bool valid = checker_pixel<U8>(P, a, x, y, x0, y0);
-    const int step = 2 << a.scale, radius = 5 * step / 2;
-    int tpitch;
-    const float* ctr = ref_center(P, pm_lds + kLdsWeightFloats, x, y, x0, y0, kChkBlockW<U8>, kChkBlockH<U8>, radius, a.scale, tpitch);
+    RefWin rw;
+    ref_window_of_pixel<SCALE, kChkBlockW<U8>, kChkBlockH<U8>>(P, x, y, x0, y0, valid, a.two_ss, a.two_sc, rw);
     if (!valid) return;
     const int W = P.W, Hh = P.H, V = P.V;
     const int idx = y * W + x;
     Rng g = rng_make(a.seed, (uint32_t)idx, a.launch);
-    RefWin rw;
-    ref_window((float4*)pm_lds + threadIdx.x, ctr, tpitch, step, radius, a.two_ss, a.two_sc, rw);
 
     // -- 8 sampling regions: position of the lowest stored cost (ref .cu:798-816)
     int pos[8];
+    if (kWavesPerSimd<U8> >= 3) keep_in_memory(reinterpret_cast<float*>(pos));
     uint32_t flags = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -297,6 +275,11 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
     float tmpw[MAXV];
     float probs[MAXV];
     float view_w[MAXV];
+    if (kWavesPerSimd<U8> >= 3) {  // 168 registers: the per-view vectors stay in private memory (one access per evaluation)
+        keep_in_memory(reinterpret_cast<float*>(cnt));
+        keep_in_memory(tmpw);
+        keep_in_memory(view_w);
+    }
     for (int v = 0; v < V; ++v) {
         cnt[v] = 0;
         tmpw[v] = 0.0f;
@@ -306,14 +289,14 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
     for (int v = 0; v < MAXV; ++v) view_w[v] = 0.0f;
     const float thr = 0.8f * d_exp((float)(a.iter * a.iter) / (-90.0f));
 
-    const float4 cur = S.planes[idx];
+    // the pixel's current plane is read where it is needed (slots 8 and 9) instead of being carried through phase A
     const float depth_sigma = (a.depth_max - a.depth_min) / 64.0f;
     const float two_ds2 = (2.0f * depth_sigma) * depth_sigma;
     const float angle_sigma = 0.08726646f;
     const float two_as2 = (2.0f * angle_sigma) * angle_sigma;
     const float beta = 0.18f;
 
-    float4 plane_now = cur, pp = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 plane_now = make_float4(0.f, 0.f, 0.f, 0.f), pp = make_float4(0.f, 0.f, 0.f, 0.f);
     float depth_now = 0.0f, cost_now = 0.0f, geom_now = 0.0f, restricted_cost = 0.0f, weight_norm = 0.0f;
     float depth_prior = 0.0f, cand_depth = 0.0f;
     // The ingredients of the five refinement candidates are drawn together (the order of the random draws is the
@@ -332,27 +315,42 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
     int min_idx = 0;
     bool masked = false;
 
-    // ---- phase A: the 8 propagated candidates against every view (ref .cu:798-819).  Two loops over ONE kind of work each
-    // (instead of one loop over 14 slots) keep the state of the later phases -- accepted plane, refinement candidates, prior --
-    // out of the registers while the candidates are evaluated, and the other way round.
+    // ---- phase A: the 8 propagated candidates against every view (ref .cu:798-819), VIEW BY VIEW: the eight evaluations of
+    // a view follow each other, so that a wave keeps sampling one source texture (the candidates are the planes of
+    // neighbouring pixels and land close to each other in it: the later ones find their texels in the L1) instead of walking
+    // through all textures once per candidate; the per-view statistics (good / bad counts, weight sum) become two scalars.
+    // The candidates' m vectors wait in private memory (fetched one evaluation ahead).
+    float cand_m[8 * 3];
+    keep_in_memory(cand_m);
     for (int slot = 0; slot < 8; ++slot) {
-        const bool active = (flags >> slot) & 1u;
-        const float4 pl = active ? S.planes[pos[slot]] : make_float4(0.f, 0.f, 0.f, 1.f);
-        float m0, m1, m2;
-        plane_to_m(P, pl, m0, m1, m2);
-        for (int v = 0; v < V; ++v) {
+        if ((flags >> slot) & 1u) {
+            float m0, m1, m2;
+            plane_to_m(P, S.planes[pos[slot]], m0, m1, m2);
+            cand_m[3 * slot] = m0, cand_m[3 * slot + 1] = m1, cand_m[3 * slot + 2] = m2;
+        }
+    }
+    for (int v = 0; v < V; ++v) {
+        int cn = 0;       // good count | bad count << 8   (ref .cu:834-845)
+        float tw = 0.0f;
+        float n0 = cand_m[0], n1 = cand_m[1], n2 = cand_m[2];
+        for (int slot = 0; slot < 8; ++slot) {
+            const float m0 = n0, m1 = n1, m2 = n2;
+            const int nxt = 3 * (slot < 7 ? slot + 1 : slot);
+            n0 = cand_m[nxt], n1 = cand_m[nxt + 1], n2 = cand_m[nxt + 2];
             float c;
-            if (active)
-                c = ncc_cost<U8>(P.views[v], rw, x, y, step, radius, m0, m1, m2);
+            if ((flags >> slot) & 1u)
+                c = ncc_cost<U8, SCALE>(P.views[v], rw, x, y, m0, m1, m2);
             else
                 c = (slot == 0 && v == 0) ? 2.0f : 0.0f;  // `= {2.0f}` initialiser quirk, ref .cu:795
             cost_arr[slot * MAXV + v] = c;
             if (c < thr) {
-                tmpw[v] += d_exp_inrange((c * c) / (-0.18f));  // c in [0, 2]: argument in [-22.3, 0]
-                cnt[v] += 1;
+                tw += d_exp_inrange((c * c) / (-0.18f));  // c in [0, 2]: argument in [-22.3, 0]
+                cn += 1;
             }
-            if (c > 1.2f) cnt[v] += 256;
+            if (c > 1.2f) cn += 256;
         }
+        cnt[v] = cn;
+        tmpw[v] = tw;
     }
     {
     // ---- view weights (ref .cu:821-878)
@@ -433,139 +431,180 @@ __global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_update(const Problem
     }
     }
 
-    // ---- phase B: the current plane under the new weights (slot 8), then the 5 refinement candidates (slots 9..13).  From
-    // here on a view with weight 0 contributes exactly +0.0 to every sum (all costs are finite), so its evaluation is dead
-    // work; the reference computes it regardless (ref .cu:681,903).
-    for (int slot = 8; slot < 14; ++slot) {
-        float4 pl;
-        if (slot == 8) {
-            pl = cur;
-        } else {
-            if (slot == 9) {
-                // ---- acceptance of the best propagated neighbour (ref .cu:921-991)
-                depth_now = depth_from_plane(P, cur, x, y);
-                const int idx_a = pinned_here(idx);
-                if (PRIOR) pp = S.prior[idx_a];
-                masked = PRIOR && S.mask[idx_a] > 0;
-                if (PRIOR && !GEOM) {
-                    depth_prior = depth_from_plane(P, pp, x, y);
-                    if (masked) {
-                        float rfc[8];
-                        for (int i = 0; i < 8; ++i) {
-                            rfc[i] = 0.0f;
-                            if ((flags >> i) & 1u) {
-                                const float4 cpl = S.planes[pinned_here(pos[i])];
-                                const float di = depth_from_plane(P, cpl, x, y);
-                                const float ac = (pp.x * cpl.x + pp.y * cpl.y) + pp.z * cpl.z;
-                                const float pr = prior_term<kGeomCall>(di - depth_prior, ac, two_ds2, two_as2);
-                                const float fci = final_costs[i];
-                                rfc[i] = d_exp(-fci * fci / beta) * pr;
-                            }
-                        }
-                        int max_idx = 0;
-                        float mc = rfc[0];
-                        for (int i = 1; i < 8; ++i)
-                            if (rfc[i] >= mc) {
-                                mc = rfc[i];
-                                max_idx = i;
-                            }
-                        const float ac = (pp.x * cur.x + pp.y * cur.y) + pp.z * cur.z;
-                        const float pr = prior_term<kGeomCall>(depth_now - depth_prior, ac, two_ds2, two_as2);
-                        const float rc_now = d_exp(-cost_now * cost_now / beta) * pr;
-                        if ((flags >> max_idx) & 1u) {
-                            const float4 cpl = S.planes[pinned_here(pos[max_idx])];
-                            const float db = depth_from_plane(P, cpl, x, y);
-                            if (db >= a.depth_min && db <= a.depth_max && rfc[max_idx] > rc_now) {
-                                // ref .cu:950/961: the shadowed depth_now keeps the old plane's depth
-                                plane_now = cpl;
-                                restricted_cost = rfc[max_idx];
-                                S.sel[idx_a] = temp_sel;
-                            }
-                        }
-                    } else if ((flags >> min_idx) & 1u) {
-                        const float4 cpl = S.planes[pinned_here(pos[min_idx])];
-                        const float db = depth_from_plane(P, cpl, x, y);
-                        if (db >= a.depth_min && db <= a.depth_max && final_costs[min_idx] < cost_now) {
-                            depth_now = db;
-                            plane_now = cpl;
-                        }
-                    }
-                }
-                if (!PRIOR && ((flags >> min_idx) & 1u)) {
-                    const float4 cpl = S.planes[pinned_here(pos[min_idx])];
-                    const float db = depth_from_plane(P, cpl, x, y);
-                    if (db >= a.depth_min && db <= a.depth_max && final_costs[min_idx] < cost_now) {
-                        depth_now = db;
-                        plane_now = cpl;
-                        cost_now = final_costs[min_idx];
-                        S.sel[idx_a] = temp_sel;
-                    }
-                }
-                // ---- refinement candidates (ref .cu:644-675)
-                const float perturbation = 0.02f;
-                float depth_rand;
-                float4 n_rand;
-                if (masked) {
-                    // ref .cu:651-660: the prior-guided draw is overwritten below (missing else), its random numbers are still consumed
-                    depth_prior = depth_from_plane(P, pp, x, y);
-                    depth_rand = (rng_uniform(g) * 6.0f) * depth_sigma + (depth_prior - 3.0f * depth_sigma);
-                    n_rand = perturbed_normal(P, x, y, pp, g, angle_sigma);
-                }
-                depth_rand = rng_uniform(g) * (a.depth_max - a.depth_min) + a.depth_min;
-                n_rand = random_normal(P, x, y, g);
-                const float dmin_p = (1.0f - perturbation) * depth_now;
-                const float dmax_p = (1.0f + perturbation) * depth_now;
-                const float depth_pert = rng_uniform(g) * (dmax_p - dmin_p) + dmin_p;
-                const float4 n_pert = perturbed_normal(P, x, y, plane_now, g, 0.06283185f);
-                park_n[0] = plane_now.x, park_n[1] = plane_now.y, park_n[2] = plane_now.z;
-                park_n[3] = n_rand.x, park_n[4] = n_rand.y, park_n[5] = n_rand.z;
-                park_n[6] = n_pert.x, park_n[7] = n_pert.y, park_n[8] = n_pert.z;
-                park_d[0] = depth_now, park_d[1] = depth_rand, park_d[2] = depth_pert;
-            }
-            // candidates: (d_rand,n) (d,n_rand) (d_rand,n_rand) (d,n_pert) (d_pert,n)   ref .cu:674-675
-            const int ci = slot - 9;
-            const int ni = 3 * ((ci == 1 || ci == 2) ? 1 : (ci == 3 ? 2 : 0));
-            pl.x = park_n[ni], pl.y = park_n[ni + 1], pl.z = park_n[ni + 2];
-            cand_depth = park_d[(ci == 0 || ci == 2) ? 1 : (ci == 4 ? 2 : 0)];
-            pl.w = plane_offset(P, x, y, cand_depth, pl);
-        }
-
+    // ---- phase B: the current plane under the new weights (ref .cu:901-913), the acceptance of the best neighbour, then the
+    // 5 refinement candidates (ref .cu:642-722).  From here on a view with weight 0 contributes exactly +0.0 to every sum (all
+    // costs are finite), so its evaluation is dead work; the reference computes it regardless (ref .cu:681,903).
+    {
+        const float4 pl = S.planes[pinned_here(idx)];
+        plane_now = pl;
         float m0, m1, m2;
         plane_to_m(P, pl, m0, m1, m2);
         GeomPoint gp{0.f, 0.f, 0.f};
         if (GEOM) gp = geom_world_point(P, pl, x, y);
         float tc = 0.0f, tg = 0.0f;
+        float w_next = view_w[0];  // one view ahead: hides the latency of private memory
         for (int v = 0; v < V; ++v) {
-            if (!(view_w[v] > 0.0f)) continue;
-            const float c = ncc_cost<U8>(P.views[v], rw, x, y, step, radius, m0, m1, m2);
+            const float w = w_next;
+            w_next = view_w[v + 1 < MAXV ? v + 1 : v];
+            if (!(w > 0.0f)) continue;
+            const float c = ncc_cost<U8, SCALE>(P.views[v], rw, x, y, m0, m1, m2);
             if (GEOM) {
                 const float gt = 0.2f * geom_cost_view<kGeomCall>(P, P.views[v], gp, x, y);
-                tc += view_w[v] * (c + gt);
-                tg += (slot == 8 ? view_w[v] : view_w[slot - 9]) * gt;  // refinement: candidate index used as view index, ref .cu:689
+                tc += w * (c + gt);
+                tg += w * gt;
             } else {
-                tc += view_w[v] * c;
+                tc += w * c;
             }
         }
-        if (slot == 8) {
-            cost_now = tc / weight_norm;
-            if (GEOM) geom_now = tg / weight_norm;
-        } else if (slot > 8) {
-            tc /= weight_norm;
-            if (GEOM) tg /= weight_norm;
-            const float db = depth_from_plane(P, pl, x, y);
-            if (masked) {
-                const float ac = (pp.x * pl.x + pp.y * pl.y) + pp.z * pl.z;
-                const float pr = prior_term<kGeomCall>(cand_depth - depth_prior, ac, two_ds2, two_as2);
-                const float rtc = d_exp(-tc * tc / beta) * pr;
-                if (db >= a.depth_min && db <= a.depth_max && rtc > restricted_cost) {
-                    plane_now = pl;
-                    cost_now = tc;
+        cost_now = tc / weight_norm;
+        if (GEOM) geom_now = tg / weight_norm;
+    }
+    {
+    // ---- acceptance of the best propagated neighbour (ref .cu:921-991)
+    const float4 cur = plane_now;  // still the plane the pixel came in with
+    depth_now = depth_from_plane(P, cur, x, y);
+    const int idx_a = pinned_here(idx);
+    if (PRIOR) pp = S.prior[idx_a];
+    masked = PRIOR && S.mask[idx_a] > 0;
+    if (PRIOR && !GEOM) {
+        depth_prior = depth_from_plane(P, pp, x, y);
+        if (masked) {
+            float rfc[8];
+            for (int i = 0; i < 8; ++i) {
+                rfc[i] = 0.0f;
+                if ((flags >> i) & 1u) {
+                    const float4 cpl = S.planes[pinned_here(pos[i])];
+                    const float di = depth_from_plane(P, cpl, x, y);
+                    const float ac = (pp.x * cpl.x + pp.y * cpl.y) + pp.z * cpl.z;
+                    const float pr = prior_term<kPriorCall>(di - depth_prior, ac, two_ds2, two_as2);
+                    const float fci = final_costs[i];
+                    rfc[i] = d_exp(-fci * fci / beta) * pr;
                 }
-            } else if (db >= a.depth_min && db <= a.depth_max && tc < cost_now) {
+            }
+            int max_idx = 0;
+            float mc = rfc[0];
+            for (int i = 1; i < 8; ++i)
+                if (rfc[i] >= mc) {
+                    mc = rfc[i];
+                    max_idx = i;
+                }
+            const float ac = (pp.x * cur.x + pp.y * cur.y) + pp.z * cur.z;
+            const float pr = prior_term<kPriorCall>(depth_now - depth_prior, ac, two_ds2, two_as2);
+            const float rc_now = d_exp(-cost_now * cost_now / beta) * pr;
+            if ((flags >> max_idx) & 1u) {
+                const float4 cpl = S.planes[pinned_here(pos[max_idx])];
+                const float db = depth_from_plane(P, cpl, x, y);
+                if (db >= a.depth_min && db <= a.depth_max && rfc[max_idx] > rc_now) {
+                    // ref .cu:950/961: the shadowed depth_now keeps the old plane's depth
+                    plane_now = cpl;
+                    restricted_cost = rfc[max_idx];
+                    S.sel[idx_a] = temp_sel;
+                }
+            }
+        } else if ((flags >> min_idx) & 1u) {
+            const float4 cpl = S.planes[pinned_here(pos[min_idx])];
+            const float db = depth_from_plane(P, cpl, x, y);
+            if (db >= a.depth_min && db <= a.depth_max && final_costs[min_idx] < cost_now) {
+                depth_now = db;
+                plane_now = cpl;
+            }
+        }
+    }
+    if (!PRIOR && ((flags >> min_idx) & 1u)) {
+        const float4 cpl = S.planes[pinned_here(pos[min_idx])];
+        const float db = depth_from_plane(P, cpl, x, y);
+        if (db >= a.depth_min && db <= a.depth_max && final_costs[min_idx] < cost_now) {
+            depth_now = db;
+            plane_now = cpl;
+            cost_now = final_costs[min_idx];
+            S.sel[idx_a] = temp_sel;
+        }
+    }
+    // ---- refinement candidates (ref .cu:644-675)
+    const float perturbation = 0.02f;
+    float depth_rand;
+    float4 n_rand;
+    if (masked) {
+        // ref .cu:651-660: the prior-guided draw is overwritten below (missing else), its random numbers are still consumed
+        depth_prior = depth_from_plane(P, pp, x, y);
+        depth_rand = (rng_uniform(g) * 6.0f) * depth_sigma + (depth_prior - 3.0f * depth_sigma);
+        n_rand = perturbed_normal(P, x, y, pp, g, angle_sigma);
+    }
+    depth_rand = rng_uniform(g) * (a.depth_max - a.depth_min) + a.depth_min;
+    n_rand = random_normal(P, x, y, g);
+    const float dmin_p = (1.0f - perturbation) * depth_now;
+    const float dmax_p = (1.0f + perturbation) * depth_now;
+    const float depth_pert = rng_uniform(g) * (dmax_p - dmin_p) + dmin_p;
+    const float4 n_pert = perturbed_normal(P, x, y, plane_now, g, 0.06283185f);
+    park_n[0] = plane_now.x, park_n[1] = plane_now.y, park_n[2] = plane_now.z;
+    park_n[3] = n_rand.x, park_n[4] = n_rand.y, park_n[5] = n_rand.z;
+    park_n[6] = n_pert.x, park_n[7] = n_pert.y, park_n[8] = n_pert.z;
+    park_d[0] = depth_now, park_d[1] = depth_rand, park_d[2] = depth_pert;
+    }
+    // candidates: (d_rand,n) (d,n_rand) (d_rand,n_rand) (d,n_pert) (d_pert,n)   ref .cu:674-675.  Their evaluations do not depend
+    // on each other (only the acceptance below is sequential), so they too run view by view.
+    float ref_m[5 * 3], ref_gp[5 * 3], tcs[5], tgs[5];
+    keep_in_memory(ref_m);
+    if (GEOM) keep_in_memory(ref_gp);
+    for (int ci = 0; ci < 5; ++ci) {
+        const int ni = 3 * ((ci == 1 || ci == 2) ? 1 : (ci == 3 ? 2 : 0));
+        float4 pl;
+        pl.x = park_n[ni], pl.y = park_n[ni + 1], pl.z = park_n[ni + 2];
+        pl.w = plane_offset(P, x, y, park_d[(ci == 0 || ci == 2) ? 1 : (ci == 4 ? 2 : 0)], pl);
+        float m0, m1, m2;
+        plane_to_m(P, pl, m0, m1, m2);
+        ref_m[3 * ci] = m0, ref_m[3 * ci + 1] = m1, ref_m[3 * ci + 2] = m2;
+        if (GEOM) {
+            const GeomPoint gp = geom_world_point(P, pl, x, y);
+            ref_gp[3 * ci] = gp.w0, ref_gp[3 * ci + 1] = gp.w1, ref_gp[3 * ci + 2] = gp.w2;
+        }
+        tcs[ci] = 0.0f;
+        tgs[ci] = 0.0f;
+    }
+    {
+        float w_next = view_w[0];
+        for (int v = 0; v < V; ++v) {
+            const float w = w_next;
+            w_next = view_w[v + 1 < MAXV ? v + 1 : v];
+            if (!(w > 0.0f)) continue;
+            float n0 = ref_m[0], n1 = ref_m[1], n2 = ref_m[2];
+            for (int ci = 0; ci < 5; ++ci) {
+                const float m0 = n0, m1 = n1, m2 = n2;
+                const int nxt = 3 * (ci < 4 ? ci + 1 : ci);
+                n0 = ref_m[nxt], n1 = ref_m[nxt + 1], n2 = ref_m[nxt + 2];
+                const float c = ncc_cost<U8, SCALE>(P.views[v], rw, x, y, m0, m1, m2);
+                if (GEOM) {
+                    const GeomPoint gp{ref_gp[3 * ci], ref_gp[3 * ci + 1], ref_gp[3 * ci + 2]};
+                    const float gt = 0.2f * geom_cost_view<kGeomCall>(P, P.views[v], gp, x, y);
+                    tcs[ci] += w * (c + gt);
+                    tgs[ci] += view_w[ci] * gt;  // the candidate index used as view index, ref .cu:689
+                } else {
+                    tcs[ci] += w * c;
+                }
+            }
+        }
+    }
+    for (int ci = 0; ci < 5; ++ci) {
+        const int ni = 3 * ((ci == 1 || ci == 2) ? 1 : (ci == 3 ? 2 : 0));
+        float4 pl;
+        pl.x = park_n[ni], pl.y = park_n[ni + 1], pl.z = park_n[ni + 2];
+        cand_depth = park_d[(ci == 0 || ci == 2) ? 1 : (ci == 4 ? 2 : 0)];
+        pl.w = plane_offset(P, x, y, cand_depth, pl);
+        const float tc = tcs[ci] / weight_norm;
+        const float tg = GEOM ? tgs[ci] / weight_norm : 0.0f;
+        const float db = depth_from_plane(P, pl, x, y);
+        if (masked) {
+            const float ac = (pp.x * pl.x + pp.y * pl.y) + pp.z * pl.z;
+            const float pr = prior_term<kPriorCall>(cand_depth - depth_prior, ac, two_ds2, two_as2);
+            const float rtc = d_exp(-tc * tc / beta) * pr;
+            if (db >= a.depth_min && db <= a.depth_max && rtc > restricted_cost) {
                 plane_now = pl;
                 cost_now = tc;
-                geom_now = tg;
             }
+        } else if (db >= a.depth_min && db <= a.depth_max && tc < cost_now) {
+            plane_now = pl;
+            cost_now = tc;
+            geom_now = tg;
         }
     }
     const int idx_o = pinned_here(idx);
@@ -661,8 +700,13 @@ __global__ void k_pack_quads_u8(const unsigned char* __restrict__ src, int w, in
     const int t00 = src[(long)y * w + x], t10 = src[(long)y * w + x1];
     const int t01 = src[(long)y1 * w + x], t11 = src[(long)y1 * w + x1];
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#ifdef PM_EXP_INTERP3
+    const h2 lo = {(_Float16)(float)t00, (_Float16)(float)(t01 - t00)};
+    const h2 hi = {(_Float16)(float)(t10 - t00), (_Float16)(float)((t11 - t01) - (t10 - t00))};
+#else
     const h2 lo = {(_Float16)(float)t00, (_Float16)(float)t01};                  // exact: integers up to 255
     const h2 hi = {(_Float16)(float)(t10 - t00), (_Float16)(float)(t11 - t01)};  // exact: |difference| <= 255
+#endif
     dst[(long)y * w + x] = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
 }
 
@@ -672,7 +716,11 @@ __global__ void k_pack_quads_f32(const float* __restrict__ src, int w, int h, fl
     if (x >= w || y >= h) return;
     const int x1 = x + 1 > w - 1 ? w - 1 : x + 1, y1 = y + 1 > h - 1 ? h - 1 : y + 1;
     const float t00 = src[(long)y * w + x], t10 = src[(long)y * w + x1], t01 = src[(long)y1 * w + x], t11 = src[(long)y1 * w + x1];
+#ifdef PM_EXP_INTERP3
+    dst[(long)y * w + x] = make_float4(t00, t10 - t00, t01 - t00, (t11 - t01) - (t10 - t00));
+#else
     dst[(long)y * w + x] = make_float4(t00, t10 - t00, t01, t11 - t01);
+#endif
 }
 
 __global__ void k_export_depth(const float4* __restrict__ planes, float* __restrict__ out, int n) {
@@ -681,23 +729,20 @@ __global__ void k_export_depth(const float4* __restrict__ planes, float* __restr
 }
 
 // probe: nh planes per pixel ([nh][H][W]) against every view; out [nh][V][H][W]
-template <int MAXV, bool U8>
-__global__ __launch_bounds__(256, PM_WAVES_PER_SIMD) void k_eval_ncc(const ProblemDev* __restrict__ Pp, const float4* __restrict__ planes, int nh, float* __restrict__ out, LaunchArgs a) {
+template <int MAXV, bool U8, int SCALE>
+__global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_eval_ncc(const ProblemDev* __restrict__ Pp, const float4* __restrict__ planes, int nh, float* __restrict__ out, LaunchArgs a) {
     const ProblemDev& P = *Pp;
     int x, y, x0, y0;
     const bool valid = dense_pixel(P, x, y, x0, y0);
-    const int step = 2 << a.scale, radius = 5 * step / 2;
-    int tpitch;
-    const float* ctr = ref_center(P, pm_lds + kLdsWeightFloats, x, y, x0, y0, 16, 16, radius, a.scale, tpitch);
+    RefWin rw;
+    ref_window_of_pixel<SCALE, 16, 16>(P, x, y, x0, y0, valid, a.two_ss, a.two_sc, rw);
     if (!valid) return;
     const int idx = y * P.W + x;
-    RefWin rw;
-    ref_window((float4*)pm_lds + threadIdx.x, ctr, tpitch, step, radius, a.two_ss, a.two_sc, rw);
     const long wh = (long)P.W * P.H;
     for (int h = 0; h < nh; ++h) {
         float m0, m1, m2;
         plane_to_m(P, planes[h * wh + idx], m0, m1, m2);
-        for (int v = 0; v < P.V; ++v) out[((long)h * P.V + v) * wh + idx] = ncc_cost<U8>(P.views[v], rw, x, y, step, radius, m0, m1, m2);
+        for (int v = 0; v < P.V; ++v) out[((long)h * P.V + v) * wh + idx] = ncc_cost<U8, SCALE>(P.views[v], rw, x, y, m0, m1, m2);
     }
 }
 

@@ -117,7 +117,7 @@ class HipPatchMatch(_abi.PatchMatchHandle):
 
     def eval_ncc_multi(self, params, planes_cam, scale, mapping=0):
         """ComputeBilateralNCC of nh planes per pixel ([nh][H][W][4]) against every view -> ([nh][V][H][W], kernel ms);
-        mapping 0 = one thread per pixel, 1..4 = cooperative lane groups (include/mpmvs.h)"""
+        mapping 0 = one thread per pixel (the only one, include/mpmvs.h)"""
         import numpy as np
         p = np.ascontiguousarray(planes_cam, np.float32)
         nh = p.shape[0]

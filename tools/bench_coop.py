@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""Per-evaluation time of the NCC core under the one-thread-per-pixel mapping and the cooperative lane-group mappings
-(mpmvs_eval_ncc_multi): cfg-1 scene, NH hypotheses per pixel x 8 views, true-surface planes with small perturbations."""
+"""Per-evaluation time of the NCC core alone (probe kernel k_eval_ncc through mpmvs_eval_ncc_multi): cfg-1 scene, NH hypotheses per pixel x 8 views, true-surface planes with small perturbations."""
 import importlib
 import json
 import os
@@ -20,7 +19,7 @@ def main():
     NH = int(os.environ.get("NH", "4"))
     res = {}
     fmts = os.environ.get("FORMATS", "u8,f32").split(",")
-    maps = [int(m) for m in os.environ.get("MAPPINGS", "0,1,2,3,4").split(",")]
+    maps = [int(m) for m in os.environ.get("MAPPINGS", "0").split(",")]
     scales = [int(m) for m in os.environ.get("SCALES", "0,2").split(",")]
     for quantize in [f == "u8" for f in fmts]:
         cams, imgs, gt = bench.load_scene(pm, W, H, V, quantize)
