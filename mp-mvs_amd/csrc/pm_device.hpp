@@ -407,11 +407,7 @@ PM_DEV void ref_window_of_pixel(const ProblemDev& P, int x, int y, int x0, int y
     }
 }
 
-// PM_PACKED=1 writes the tap-pair arithmetic on float2 vectors (v_pk_fma/mul_f32)
-#ifndef PM_PACKED
-#define PM_PACKED 1
-#endif
-
+// the tap-pair arithmetic is written on float2 vectors (v_pk_fma/mul_f32)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Clamp a sample coordinate to [0, hi] (hi = size - 1); NaN -> 0 (v_med3_f32 returns
@@ -454,15 +450,16 @@ PM_DEV int tex_byte_offset(const TEX& t, int iy, int ix) {
 }
 
 // Source textures ("quad-difference" texels).  Texel (x, y) of a view packs the whole bilinear footprint of the image P
-// (indices clamped to the image) in the form the interpolation consumes:
-//     (t00, d0, t01, d1) = (P[y][x], P[y][x+1] - P[y][x], P[y+1][x], P[y+1][x+1] - P[y+1][x])
-// so that ONE gather serves a tap and the horizontal interpolations are single fmas, fma(ax, d, t), with no unpacking:
-//   * fp32 format (any image): four floats, 16 bytes, one buffer_load_dwordx4.  d is the fp32 difference the canonical
-//     arithmetic defines, rounded once when the texture is packed instead of once per tap.
+// (indices clamped to the image) as the coefficients of the bilinear polynomial t00 + ax dx + ay (dy + ax dxy):
+//     t00 = P[y][x],  dx = P[y][x+1] - t00,  dy = P[y+1][x] - t00,  dxy = (P[y+1][x+1] - P[y+1][x]) - dx
+// so that ONE gather serves a tap and the interpolation is three fmas with no unpacking
+//     top = fma(ax, dx, t00);  ver = fma(ax, dxy, dy);  value = fma(ay, ver, top)
+//   * fp32 format (any image): four floats, 16 bytes, one buffer_load_dwordx4.  The differences are the fp32 differences the
+//     canonical arithmetic defines, rounded once when the texture is packed instead of once per tap.
 //   * fp16 format (every pixel of every source image an integer in [0, 255]: always true for the reference's input unless
 //     it rescales, imread(GRAYSCALE) -> convertTo(CV_32F), ref .cpp:877-882): four halfs, 8 bytes, one
-//     buffer_load_dwordx2; dword 0 = (t00, t01), dword 1 = (d0, d1).  Integers up to 255 and their differences are exact
-//     in fp16, v_fma_mix_f32 reads the half operands directly and rounds once in fp32: identical bits to the fp32 format.
+//     buffer_load_dwordx2; dword 0 = (t00, dy), dword 1 = (dx, dxy).  Integers up to 255 and these differences (|.| <= 510)
+//     are exact in fp16, v_fma_mix_f32 reads the half operands directly and rounds once in fp32: identical bits to the fp32 format.
 // The 128-bit buffer resource is wave-uniform (built from scalar loads); the 32-bit byte offset is range checked by the
 // hardware (an out-of-range offset -- impossible, the coordinate is clamped first -- would read 0 instead of faulting).
 // The gather addresses a texel by its INDEX (buffer_load ... idxen, the descriptor carries the texel size as its stride),
@@ -524,7 +521,7 @@ struct BilinearTap;
 template <>
 struct BilinearTap<false> {
     float ax, ay;
-    f32x4q q;  // (t00, d0, t01, d1)
+    f32x4q q;  // (t00, dx, dy, dxy)
     template <class TEX>
     PM_DEV void issue(const TEX& t, float sx, float sy) {
         const float cx = clamp_coord(sx, t.wm1);
@@ -543,19 +540,15 @@ struct BilinearTap<false> {
 #endif
     }
     PM_DEV float value() const {
-        const float top = __builtin_fmaf(ax, q.y, q.x);
-        const float bot = __builtin_fmaf(ax, q.w, q.z);
-#ifdef PM_EXP_INTERP3
-        return __builtin_fmaf(ay, bot, top);
-#else
-        return __builtin_fmaf(ay, bot - top, top);
-#endif
+        const float top = __builtin_fmaf(ax, q.y, q.x);  // value on the upper row
+        const float ver = __builtin_fmaf(ax, q.w, q.z);  // lower row minus upper row
+        return __builtin_fmaf(ay, ver, top);
     }
 };
 template <>
 struct BilinearTap<true> {
     float ax, ay;
-    u32x2q q;  // halfs: (t00, t01), (d0, d1)
+    u32x2q q;  // halfs: (t00, dy), (dx, dxy)
     template <class TEX>
     PM_DEV void issue(const TEX& t, float sx, float sy) {
         const float cx = clamp_coord(sx, t.wm1);
@@ -576,14 +569,10 @@ struct BilinearTap<true> {
     PM_DEV float value() const {
         // fma(ax, (float)d0, (float)t00) and the same on the high halves, the fp16 operands read in place (hipcc does not form
         // v_fma_mix_f32 from the fpext + fma pattern here)
-        float top, bot;
+        float top, ver;
         asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(top) : "v"(ax), "v"(q.y), "v"(q.x));
-        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[0,1,1]" : "=v"(bot) : "v"(ax), "v"(q.y), "v"(q.x));
-#ifdef PM_EXP_INTERP3
-        return __builtin_fmaf(ay, bot, top);
-#else
-        return __builtin_fmaf(ay, bot - top, top);
-#endif
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[0,1,1]" : "=v"(ver) : "v"(ax), "v"(q.y), "v"(q.x));
+        return __builtin_fmaf(ay, ver, top);
     }
 };
 
@@ -611,14 +600,12 @@ PM_DEV float ncc_core(const TEX& tex, float wf, float hf, float H0, float H1, fl
         const float cx = X * rz, cy = Y * rz;
         if (!(cx >= 0.0f && cx < wf && cy >= 0.0f && cy < hf)) return 2.0f;  // ref .cu:351-353
     }
-    float T1 = 0.0f, T2 = 0.0f, T3 = 0.0f;
     float racc = 0.0f;  // sum of the six column reciprocals: not finite = some column had no usable reciprocal
     const f32x2 h1 = {H1, H1}, h4 = {H4, H4}, h7 = {H7, H7};
 
     // phase 1 of window column a: warp its 6 taps as 3 packed pairs, share ONE
     // reciprocal between the six perspective divides, compute the
     // addresses and issue all gathers of the column back to back
-#if PM_PACKED
     auto issue_column = [&](int a, BilinearTap<U8>(&tap)[6]) {
         const float tx = (float)(px + a * step - radius);
         const float Cx = __builtin_fmaf(H0, tx, H2);
@@ -647,8 +634,8 @@ PM_DEV float ncc_core(const TEX& tex, float wf, float hf, float H0, float H1, fl
             tap[2 * j + 1].issue(tex, sx.y, sy.y);
         }
     };
-    // phase 2: interpolate; even/odd taps accumulate in the two halves of packed registers
-#ifdef PM_EXP_GLOBALACC
+    // phase 2: interpolate; the even taps (b = 0, 2, 4) and the odd taps of ALL columns accumulate in the two halves of packed
+    // registers and meet once, at the end of the window
     f32x2 A1 = {0.0f, 0.0f}, A2 = {0.0f, 0.0f}, A3 = {0.0f, 0.0f};
     auto consume_column = [&](const float4 (&wq)[3], const BilinearTap<U8>(&tap)[6]) {
 #pragma unroll
@@ -660,73 +647,11 @@ PM_DEV float ncc_core(const TEX& tex, float wf, float hf, float H0, float H1, fl
             A2 = __builtin_elementwise_fma(ws, sv, A2);
             A3 = __builtin_elementwise_fma(wr2, sv, A3);
         }
+        // A3 is only consumed after the variance test at the end, so the compiler would SINK its whole accumulation behind that
+        // branch: keep all 36 interpolated values alive in registers and re-read the weight records from LDS there.  Pin it
+        // to the column it belongs to.
         asm volatile("" : "+v"(A3));
     };
-#else
-    auto consume_column = [&](const float4 (&wq)[3], const BilinearTap<U8>(&tap)[6]) {
-        f32x2 A1 = {0.0f, 0.0f}, A2 = {0.0f, 0.0f}, A3 = {0.0f, 0.0f};
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const f32x2 sv = {tap[2 * j].value(), tap[2 * j + 1].value()};
-            const f32x2 w2 = {wq[j].x, wq[j].y}, wr2 = {wq[j].z, wq[j].w};
-            const f32x2 ws = w2 * sv;
-            A1 = __builtin_elementwise_fma(w2, sv, A1);
-            A2 = __builtin_elementwise_fma(ws, sv, A2);
-            A3 = __builtin_elementwise_fma(wr2, sv, A3);
-        }
-        T1 += A1.x + A1.y;
-        T2 += A2.x + A2.y;
-        T3 += A3.x + A3.y;
-        // T3 is only consumed after the variance test at the end, so the compiler would SINK its whole accumulation behind that
-        // branch: keep all 36 interpolated values alive in registers (36 VGPRs in a kernel that sits at the 256 cap) and re-read
-        // the weight records from LDS there.  Pin it to the column it belongs to.
-        asm volatile("" : "+v"(T3));
-    };
-#endif
-#else
-    auto issue_column = [&](int a, BilinearTap<U8>(&tap)[6]) {
-        const float tx = (float)(px + a * step - radius);
-        const float Cx = __builtin_fmaf(H0, tx, H2);
-        const float Cy = __builtin_fmaf(H3, tx, H5);
-        const float Cz = __builtin_fmaf(H6, tx, H8);
-        float X[6], Y[6], Z[6];
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            const float ty = (float)(py + b * step - radius);
-            X[b] = __builtin_fmaf(H1, ty, Cx);
-            Y[b] = __builtin_fmaf(H4, ty, Cy);
-            Z[b] = __builtin_fmaf(H7, ty, Cz);
-        }
-        const float q0 = Z[0] * Z[1], q1 = Z[2] * Z[3], q2 = Z[4] * Z[5];
-        const float t = q0 * q1, u = q1 * q2, v = q0 * q2;
-        const float r = d_rcp(t * q2);
-        racc += r;
-        const float iq[3] = {r * u, r * v, r * t};
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float i0 = iq[j] * Z[2 * j + 1], i1 = iq[j] * Z[2 * j];
-            tap[2 * j].issue(tex, X[2 * j] * i0, Y[2 * j] * i0);
-            tap[2 * j + 1].issue(tex, X[2 * j + 1] * i1, Y[2 * j + 1] * i1);
-        }
-    };
-    auto consume_column = [&](const float4 (&wq)[3], const BilinearTap<U8>(&tap)[6]) {
-        float E1 = 0.0f, E2 = 0.0f, E3 = 0.0f, O1 = 0.0f, O2 = 0.0f, O3 = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float se = tap[2 * j].value(), so = tap[2 * j + 1].value();
-            const float wse = wq[j].x * se, wso = wq[j].y * so;
-            E1 = __builtin_fmaf(wq[j].x, se, E1);
-            O1 = __builtin_fmaf(wq[j].y, so, O1);
-            E2 = __builtin_fmaf(wse, se, E2);
-            O2 = __builtin_fmaf(wso, so, O2);
-            E3 = __builtin_fmaf(wq[j].z, se, E3);
-            O3 = __builtin_fmaf(wq[j].w, so, O3);
-        }
-        T1 += E1 + O1;
-        T2 += E2 + O2;
-        T3 += E3 + O3;
-    };
-#endif
     // software pipeline over the 6 columns: the gathers of column a+1 are in flight
     // while column a is interpolated, so a wave never drains its loads; the LDS
     // weight records of a column are fetched one column ahead for the same reason
@@ -749,11 +674,7 @@ PM_DEV float ncc_core(const TEX& tex, float wf, float hf, float H0, float H1, fl
         }
         consume_column(wB, tapB);
     }
-#if PM_PACKED && defined(PM_EXP_GLOBALACC)
-    T1 = A1.x + A1.y;
-    T2 = A2.x + A2.y;
-    T3 = A3.x + A3.y;
-#endif
+    const float T1 = A1.x + A1.y, T2 = A2.x + A2.y, T3 = A3.x + A3.y;
     if (rcp_sum_not_finite(racc)) return 2.0f;  // no usable warp (plane through the camera centre)
     const float ms = T1 * rw.inv_w, mss = T2 * rw.inv_w, mrs = T3 * rw.inv_w;
     const float var_s = __builtin_fmaf(-ms, ms, mss);

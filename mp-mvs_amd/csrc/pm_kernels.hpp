@@ -59,7 +59,7 @@ __device__ constexpr int kNumDirs[8] = {12, 12, 12, 12, 10, 10, 10, 10};
 // (8 bytes) 2 / 4 / 8 / 16 rows: 4.00 / 3.66 / 3.50 / 3.45 ms; fp32 texels (16 bytes) 4 / 8 / 16 / 32 rows: 4.72 / 4.47 /
 // 4.57 / 5.90 ms.  (Round 1, 4-byte u8 quads: 4 rows 3.85, 8 rows 3.89, 2 rows 3.98, 16 rows 4.84.)
 #ifndef PM_WAVE_ROWS
-#define PM_WAVE_ROWS 16
+#define PM_WAVE_ROWS 8
 #endif
 #ifndef PM_WAVE_ROWS_F32
 #define PM_WAVE_ROWS_F32 8
@@ -700,13 +700,8 @@ __global__ void k_pack_quads_u8(const unsigned char* __restrict__ src, int w, in
     const int t00 = src[(long)y * w + x], t10 = src[(long)y * w + x1];
     const int t01 = src[(long)y1 * w + x], t11 = src[(long)y1 * w + x1];
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-#ifdef PM_EXP_INTERP3
-    const h2 lo = {(_Float16)(float)t00, (_Float16)(float)(t01 - t00)};
-    const h2 hi = {(_Float16)(float)(t10 - t00), (_Float16)(float)((t11 - t01) - (t10 - t00))};
-#else
-    const h2 lo = {(_Float16)(float)t00, (_Float16)(float)t01};                  // exact: integers up to 255
-    const h2 hi = {(_Float16)(float)(t10 - t00), (_Float16)(float)(t11 - t01)};  // exact: |difference| <= 255
-#endif
+    const h2 lo = {(_Float16)(float)t00, (_Float16)(float)(t01 - t00)};                           // exact: integers, |.| <= 255
+    const h2 hi = {(_Float16)(float)(t10 - t00), (_Float16)(float)((t11 - t01) - (t10 - t00))};  // exact: integers, |.| <= 510
     dst[(long)y * w + x] = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
 }
 
@@ -716,11 +711,7 @@ __global__ void k_pack_quads_f32(const float* __restrict__ src, int w, int h, fl
     if (x >= w || y >= h) return;
     const int x1 = x + 1 > w - 1 ? w - 1 : x + 1, y1 = y + 1 > h - 1 ? h - 1 : y + 1;
     const float t00 = src[(long)y * w + x], t10 = src[(long)y * w + x1], t01 = src[(long)y1 * w + x], t11 = src[(long)y1 * w + x1];
-#ifdef PM_EXP_INTERP3
     dst[(long)y * w + x] = make_float4(t00, t10 - t00, t01 - t00, (t11 - t01) - (t10 - t00));
-#else
-    dst[(long)y * w + x] = make_float4(t00, t10 - t00, t01, t11 - t01);
-#endif
 }
 
 __global__ void k_export_depth(const float4* __restrict__ planes, float* __restrict__ out, int n) {

@@ -445,9 +445,11 @@ inline float bilinear(const Image& im, float sx, float sy) {
     const int ix = (int)fx, iy = (int)fy;
     const float t00 = im.at(ix, iy), t10 = im.at(ix + 1, iy);
     const float t01 = im.at(ix, iy + 1), t11 = im.at(ix + 1, iy + 1);
-    const float top = fmaf(ax, t10 - t00, t00);
-    const float bot = fmaf(ax, t11 - t01, t01);
-    return fmaf(ay, bot - top, top);
+    // the bilinear polynomial t00 + ax dx + ay (dy + ax dxy) in three fmas
+    const float dx = t10 - t00, dy = t01 - t00, dxy = (t11 - t01) - dx;
+    const float top = fmaf(ax, dx, t00);
+    const float ver = fmaf(ax, dxy, dy);
+    return fmaf(ay, ver, top);
 }
 
 // plane -> m = (n^T K_r^-1) / d   (per hypothesis, shared by all views)
@@ -476,8 +478,10 @@ inline float ncc_cost(const Ctx& c, const RefWin& rw, int px, int py, const floa
         const float cx = X * rz, cy = Y * rz;
         if (!(cx >= 0.0f && cx < vc.wf && cy >= 0.0f && cy < vc.hf)) return 2.0f;  // ref .cu:351-353
     }
-    float T1 = 0.0f, T2 = 0.0f, T3 = 0.0f;
     float racc = 0.0f;
+    // the even taps (b = 0, 2, 4) and the odd taps of all six columns accumulate separately (the GPU keeps them in the two
+    // halves of packed fp32 registers) and are added once, at the end of the window
+    float E1 = 0.0f, E2 = 0.0f, E3 = 0.0f, O1 = 0.0f, O2 = 0.0f, O3 = 0.0f;
     for (int a = 0; a < 6; ++a) {
         const float tx = (float)(px + rw.dx[a]);
         const float Cx = fmaf(Hm[0], tx, Hm[2]);
@@ -507,9 +511,6 @@ inline float ncc_cost(const Ctx& c, const RefWin& rw, int px, int py, const floa
             I[4] = iq2 * Z[5];
             I[5] = iq2 * Z[4];
         }
-        // even and odd taps of the column accumulate separately (the GPU keeps
-        // them in the two halves of packed fp32 registers), then are added
-        float E1 = 0.0f, E2 = 0.0f, E3 = 0.0f, O1 = 0.0f, O2 = 0.0f, O3 = 0.0f;
         for (int b = 0; b < 6; ++b) {
             const float sv = bilinear(src, X[b] * I[b], Y[b] * I[b]);
             const float w = rw.w[a * 6 + b];
@@ -524,10 +525,8 @@ inline float ncc_cost(const Ctx& c, const RefWin& rw, int px, int py, const floa
                 O3 = fmaf(rw.wr[a * 6 + b], sv, O3);
             }
         }
-        T1 += E1 + O1;
-        T2 += E2 + O2;
-        T3 += E3 + O3;
     }
+    const float T1 = E1 + O1, T2 = E2 + O2, T3 = E3 + O3;
     // near-degenerate planes (the reference divides per tap and gets garbage coordinates there): sentinel cost
     if (!std::isfinite(racc)) return 2.0f;
     const float ms = T1 * rw.inv_w, mss = T2 * rw.inv_w, mrs = T3 * rw.inv_w;
