@@ -21,6 +21,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <limits>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -90,14 +91,14 @@ inline float u2f(uint32_t u) {
     return f;
 }
 
-// reciprocal: magic-constant seed + 3 Newton steps (<= 2 ulp), sign restored.
+// reciprocal as the GPU's d_rcp returns it (hardware seed + two Newton steps; tools/verify_rcp.hip checks this rule against
+// the device for all 2^32 inputs): the correctly rounded quotient where z and 1 / z are normal, a signed zero where 1 / z
+// would be denormal, NaN for zero, denormal, infinite and NaN z.
 inline float det_rcp(float z) {
-    const float az = u2f(f2u(z) & 0x7fffffffu);
-    float r = u2f(0x7EF311C7u - f2u(az));
-    r = fmaf(r, fmaf(-az, r, 1.0f), r);
-    r = fmaf(r, fmaf(-az, r, 1.0f), r);
-    r = fmaf(r, fmaf(-az, r, 1.0f), r);
-    return u2f(f2u(r) | (f2u(z) & 0x80000000u));
+    const float az = std::fabs(z);
+    if (!(az >= 1.17549435e-38f) || az > 3.40282347e+38f) return std::numeric_limits<float>::quiet_NaN();
+    if (az > 0x1p+126f) return std::copysign(0.0f, z);
+    return 1.0f / z;
 }
 
 // fractional part as the GPU's V_FRACT_F32 computes it: x - floor(x), kept below 1
@@ -499,7 +500,7 @@ inline float ncc_cost(const Ctx& c, const RefWin& rw, int px, int py, const floa
         {
             const float q0 = Z[0] * Z[1], q1 = Z[2] * Z[3], q2 = Z[4] * Z[5];
             const float t = q0 * q1, u = q1 * q2, v = q0 * q2;
-            // det_rcp maps an infinite / NaN product to -+inf / NaN and a zero / denormal one to +-inf: the sum of the six
+            // det_rcp maps an infinite / NaN / zero / denormal product to NaN: the sum of the six
             // column reciprocals is finite exactly when every column had a usable one (checked after the loop)
             const float r = det_rcp(t * q2);
             racc += r;
