@@ -174,6 +174,11 @@ int mpmvs_eval_geom(mpmvs_ctx* ctx, const mpmvs_params* params, const void* plan
 int mpmvs_homography(mpmvs_ctx* ctx, const void* plane4, int src_view, void* H9);
 /* canonical device math, fn: 0 rcp, 1 exp, 2 sin, 3 cos, 4 acos, 5 fract */
 int mpmvs_math(int fn, const void* in, void* out, int n);
+/* exhaustive check of the kernels' reciprocal against the rule the CPU oracle implements, over all 2^32 float bit patterns
+ * (about a second): counts[0] inputs z with z and 1 / z normal, counts[1] of those whose result differs from the correctly
+ * rounded quotient 1.0f / z, counts[2] all other inputs, counts[3] of those that break the rule "signed zero where 1 / z is
+ * denormal, not finite for zero / denormal / infinite / NaN z".  counts[1] == counts[3] == 0 is what lets the oracle divide. */
+int mpmvs_verify_rcp(unsigned long long counts[4]);
 /* first n uniforms of RNG stream (seed, pixel, launch_id) */
 int mpmvs_rng(uint64_t seed, uint32_t pix, uint32_t launch_id, int n, void* out);
 

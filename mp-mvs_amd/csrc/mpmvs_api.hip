@@ -1048,6 +1048,21 @@ int mpmvs_math(int fn, const void* in, void* out, int n) {
     return rc;
 }
 
+int mpmvs_verify_rcp(unsigned long long counts[4]) {
+    if (!counts) return -1;
+    (void)hipGetLastError();
+    unsigned long long* d = nullptr;
+    if (hipMalloc(&d, 32) != hipSuccess) return -100;
+    int rc = hipMemset(d, 0, 32) == hipSuccess ? 0 : -100;
+    for (uint64_t base = 0; !rc && base < (1ULL << 32); base += (1ULL << 24)) {
+        hipLaunchKernelGGL(k_verify_rcp, dim3(1 << 16), dim3(256), 0, nullptr, (uint32_t)base, d);
+        if (hipGetLastError() != hipSuccess) rc = -100;
+    }
+    if (!rc && hipMemcpy(counts, d, 32, hipMemcpyDeviceToHost) != hipSuccess) rc = -100;
+    (void)hipFree(d);
+    return rc;
+}
+
 int mpmvs_rng(uint64_t seed, uint32_t pix, uint32_t launch_id, int n, void* out) {
     if (n <= 0) return -1;
     (void)hipGetLastError();

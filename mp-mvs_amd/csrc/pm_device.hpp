@@ -438,17 +438,16 @@ PM_DEV float ubyte_to_float(uint32_t q) {
     return f;
 }
 
-// byte offset of texel (ix, iy), 2^SHIFT bytes per texel
-// PM_DBG_ADDRMASK (measurement builds only, results are wrong): all gathers of a wave fall into a few cache lines, which
-// takes the texture path (TA / L1 / TD) out of the picture while the instruction stream stays the same
-template <int SHIFT, class TEX>
-PM_DEV int tex_byte_offset(const TEX& t, int iy, int ix) {
-    const unsigned idx = __umul24((unsigned)iy, (unsigned)t.pitch) + (unsigned)ix;
-    unsigned off = idx << SHIFT;
+// index of texel (ix, iy) in its texture.  PM_DBG_ADDRMASK (measurement builds only, results are wrong): all gathers of a wave
+// fall into a few cache lines, which takes the texture path (TA / L1 / TD) out of the picture while the instruction stream
+// stays the same
+template <class TEX>
+PM_DEV int texel_index(const TEX& t, int iy, int ix) {
+    unsigned idx = __umul24((unsigned)iy, (unsigned)t.pitch) + (unsigned)ix;  // v_mad_u32_u24
 #ifdef PM_DBG_ADDRMASK
-    off &= (unsigned)(PM_DBG_ADDRMASK);
+    idx &= (unsigned)(PM_DBG_ADDRMASK);
 #endif
-    return (int)off;
+    return (int)idx;
 }
 
 // Source textures ("quad-difference" texels).  Texel (x, y) of a view packs the whole bilinear footprint of the image P
@@ -462,11 +461,10 @@ PM_DEV int tex_byte_offset(const TEX& t, int iy, int ix) {
 //     it rescales, imread(GRAYSCALE) -> convertTo(CV_32F), ref .cpp:877-882): four halfs, 8 bytes, one
 //     buffer_load_dwordx2; dword 0 = (t00, dy), dword 1 = (dx, dxy).  Integers up to 255 and these differences (|.| <= 510)
 //     are exact in fp16, v_fma_mix_f32 reads the half operands directly and rounds once in fp32: identical bits to the fp32 format.
-// The 128-bit buffer resource is wave-uniform (built from scalar loads); the 32-bit byte offset is range checked by the
-// hardware (an out-of-range offset -- impossible, the coordinate is clamped first -- would read 0 instead of faulting).
+// The 128-bit buffer resource is wave-uniform (built from scalar loads); the texel index is range checked by the hardware
+// (an out-of-range index -- impossible, the coordinate is clamped first -- would read 0 instead of faulting).
 // The gather addresses a texel by its INDEX (buffer_load ... idxen, the descriptor carries the texel size as its stride),
-// so the address is one v_mad_u32_u24 instead of a 24-bit multiply and a shift-add (-1.2 % on k_update; -DPM_NO_IDXEN
-// builds the byte-offset form).  The descriptor is written out as four dwords because the indexed load is reached through
+// so the address is one v_mad_u32_u24 instead of a 24-bit multiply and a shift-add (-1.2 % on k_update).  The descriptor is written out as four dwords because the indexed load is reached through
 // its LLVM intrinsic (hipcc has no builtin for it); an index beyond `texels` reads 0 (cannot happen: clamped coordinates).
 typedef int i32x4q __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2q __attribute__((ext_vector_type(2)));
@@ -479,7 +477,6 @@ PM_DEV i32x4q make_indexed_rsrc(const void* base, int texel_bytes, int texels) {
 }
 
 struct SrcTex {
-    __amdgpu_buffer_rsrc_t rsrc;
     i32x4q irsrc;
     int pitch;  // texels per row (= w)
     float wm1, hm1;
@@ -490,14 +487,11 @@ PM_DEV SrcTex make_src_tex(const ViewDev& vw) {
     t.pitch = vw.pitch;
     t.wm1 = vw.wm1;
     t.hm1 = vw.hm1;
-    const int bytes = vw.pitch * vw.h * 16;
-    t.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vw.img), (short)0, bytes, 0x00020000);
     t.irsrc = make_indexed_rsrc(vw.img, 16, vw.pitch * vw.h);
     return t;
 }
 
 struct SrcTex8 {
-    __amdgpu_buffer_rsrc_t rsrc;
     i32x4q irsrc;
     int pitch;  // texels per row (= w)
     float wm1, hm1;
@@ -508,8 +502,6 @@ PM_DEV SrcTex8 make_src_tex8(const ViewDev& vw) {
     t.pitch = vw.pitch8;
     t.wm1 = vw.wm1;
     t.hm1 = vw.hm1;
-    const int bytes = vw.pitch8 * vw.h * 8;
-    t.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(vw.img8), (short)0, bytes, 0x00020000);
     t.irsrc = make_indexed_rsrc(vw.img8, 8, vw.pitch8 * vw.h);
     return t;
 }
@@ -530,15 +522,11 @@ struct BilinearTap<false> {
         const float cy = clamp_coord(sy, t.hm1);
         ax = __builtin_amdgcn_fractf(cx);  // v_fract_f32: x - floor(x), kept below 1
         ay = __builtin_amdgcn_fractf(cy);
-#if !defined(PM_NO_IDXEN) && !defined(PM_DBG_NOLOAD) && !defined(PM_DBG_ADDRMASK)
-        q = pm_struct_load_f128(t.irsrc, (int)(__umul24((unsigned)floor_to_int(cy), (unsigned)t.pitch) + (unsigned)floor_to_int(cx)), 0, 0, 0);
-        return;
-#endif
-        const int off = tex_byte_offset<4>(t, floor_to_int(cy), floor_to_int(cx));
+        const int idx = texel_index(t, floor_to_int(cy), floor_to_int(cx));
 #ifdef PM_DBG_NOLOAD  // measurement builds only (results are wrong): the instruction stream without its gathers
-        q = (f32x4q){(float)off, 1.0f, ax, ay};
+        q = (f32x4q){(float)idx, 1.0f, ax, ay};
 #else
-        q = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(t.rsrc, off, 0, 0));
+        q = pm_struct_load_f128(t.irsrc, idx, 0, 0, 0);
 #endif
     }
     PM_DEV float value() const {
@@ -557,15 +545,11 @@ struct BilinearTap<true> {
         const float cy = clamp_coord(sy, t.hm1);
         ax = __builtin_amdgcn_fractf(cx);
         ay = __builtin_amdgcn_fractf(cy);
-#if !defined(PM_NO_IDXEN) && !defined(PM_DBG_NOLOAD) && !defined(PM_DBG_ADDRMASK)
-        q = pm_struct_load_b64(t.irsrc, (int)(__umul24((unsigned)floor_to_int(cy), (unsigned)t.pitch) + (unsigned)floor_to_int(cx)), 0, 0, 0);
-        return;
-#endif
-        const int off = tex_byte_offset<3>(t, floor_to_int(cy), floor_to_int(cx));
+        const int idx = texel_index(t, floor_to_int(cy), floor_to_int(cx));
 #ifdef PM_DBG_NOLOAD  // measurement builds only (results are wrong): the instruction stream without its gathers
-        q = (u32x2q){(uint32_t)off, (uint32_t)off};
+        q = (u32x2q){(uint32_t)idx, (uint32_t)idx};
 #else
-        q = __builtin_bit_cast(u32x2q, __builtin_amdgcn_raw_buffer_load_b64(t.rsrc, off, 0, 0));
+        q = pm_struct_load_b64(t.irsrc, idx, 0, 0, 0);
 #endif
     }
     PM_DEV float value() const {

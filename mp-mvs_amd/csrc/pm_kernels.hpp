@@ -772,6 +772,27 @@ __global__ void k_math(int fn, const float* __restrict__ in, float* __restrict__
     out[i] = y;
 }
 
+// d_rcp against the rule the oracle implements (oracle/pm_oracle.cpp det_rcp), for the 2^24 bit patterns base .. base + 2^24 - 1:
+// counts[0] inputs with z and 1 / z normal, [1] of those that differ from the device's correctly rounded quotient 1.0f / z,
+// [2] other inputs, [3] of those that break the rule (signed zero where 1 / z is denormal, otherwise not finite)
+__global__ void k_verify_rcp(uint32_t base, unsigned long long* __restrict__ counts) {
+    const uint32_t bits = base + blockIdx.x * blockDim.x + threadIdx.x;
+    const float z = __uint_as_float(bits);
+    const float got = d_rcp(z);
+    const float az = __builtin_fabsf(z);
+    const bool z_normal = az >= 1.17549435e-38f && az <= 3.40282347e+38f;
+    if (z_normal && az <= 0x1p+126f) {
+        const float want = 1.0f / z;  // -fhip-fp32-correctly-rounded-divide-sqrt: IEEE
+        atomicAdd(&counts[0], 1ULL);
+        if (__float_as_uint(got) != __float_as_uint(want)) atomicAdd(&counts[1], 1ULL);
+    } else {
+        atomicAdd(&counts[2], 1ULL);
+        const bool finite = __builtin_fabsf(got) <= 3.40282347e+38f;
+        const bool ok = z_normal ? __float_as_uint(got) == (bits & 0x80000000u) : !finite;
+        if (!ok) atomicAdd(&counts[3], 1ULL);
+    }
+}
+
 __global__ void k_rng(uint64_t seed, uint32_t pix, uint32_t launch, int n, float* __restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Rng g = rng_make(seed, pix, launch);

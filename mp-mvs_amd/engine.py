@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmpmvs_hip.so")
 # entry points of include/mpmvs.h beyond the set shared with the test oracle
 _P = C.c_void_p
 _EXTRA = {
+    "verify_rcp": (C.c_int, [C.POINTER(C.c_ulonglong)]),
     "device_count": (C.c_int, []),
     "set_src_depths_device": (C.c_int, [_P, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "export_depth_device": (C.c_int, [_P, _P]),

@@ -75,6 +75,18 @@ def test_math_bit_exact(pm, oracle, engine, fn, lo, hi):
     assert_same(f"math fn {fn}", got, want)
 
 
+def test_reciprocal_exhaustive(engine):
+    """the kernels' reciprocal (hardware seed + two Newton steps) equals the IEEE quotient the oracle computes for EVERY float
+    whose reciprocal is normal, and follows the oracle's rule everywhere else: all 2^32 bit patterns, checked on the device"""
+    import ctypes
+    _, f_gpu = engine.load()
+    counts = (ctypes.c_ulonglong * 4)()
+    assert f_gpu["verify_rcp"](counts) == 0
+    normal, normal_bad, other, other_bad = list(counts)
+    assert normal + other == 2 ** 32 and normal == 4227858434
+    assert normal_bad == 0 and other_bad == 0
+
+
 def test_rng_bit_exact(pm, oracle, engine):
     _, f_gpu = engine.load()
     for seed, pix, launch in [(SEED, 0, 0), (SEED, 12345, 7), (2 ** 40 + 17, 1919999, 22)]:
