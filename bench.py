@@ -481,6 +481,9 @@ def main():
                 "algorithmic_flop_per_launch": flops_per_launch,
                 "hbm": {"achieved": round(gbps, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 5),
                         "algorithmic_bytes_per_launch": hbm_bytes_per_launch},
+                # SURVEY 8(d)'s third figure, a diagnostic at L1 / LDS level (reuse makes it exceed the HBM peak): 36 taps x 20 logical
+                # bytes (1 reference + 4 source texels, fp32) per nominal (hypothesis, view) evaluation
+                "tap_gather": {"achieved": round((W * H // 2) * 14 * V * 36 * 20 / (upd_avg_ms * 1e-3) / 1e12, 2), "unit": "TB/s (logical)"},
             },
             "kernel_ms_per_step": round(all_ms / args.steps, 3),
             "within_1pct_of_gt": round(within, 4),
