@@ -147,9 +147,10 @@ def timed_runs(pm, ctx, prm, seed, steps, bufs=None):
     upd_ms, upd_n, all_ms = 0.0, 0, 0.0
     t0 = time.perf_counter()
     for i in range(steps):
-        ctx.run(prm, seed + i)
         if bufs is not None:
-            ctx.get_into(*bufs)
+            ctx.run_into(prm, seed + i, *bufs)   # Run() incl. the D2H copies that end it (mpmvs_run_get)
+        else:
+            ctx.run(prm, seed + i)
         ms, cnt = ctx.kernel_times()
         upd_ms += ms[pm.KIND_BLACK] + ms[pm.KIND_RED]
         upd_n += cnt[pm.KIND_BLACK] + cnt[pm.KIND_RED]

@@ -144,6 +144,11 @@ int mpmvs_get_prior(mpmvs_ctx* ctx, void* prior_planes4, void* mask_u32);
  * the reference never runs that combination (ProcessProblem clears
  * geom_consistency before the prior Run(), src/PatchMatch.cpp:535). */
 int mpmvs_run(mpmvs_ctx* ctx, const mpmvs_params* params, uint64_t seed);
+/* Run() together with the device-to-host copies that end it in the reference (src/PatchMatch.cu:1246-1251): planes (float4 =
+ * world normal + depth), costs and -- geometric consistency only -- geometric costs into host buffers of W*H elements (each
+ * may be NULL; pinned memory makes the copies asynchronous).  The cost maps are final after the last update launch and
+ * travel while the median filter still runs.  Same results as mpmvs_run followed by mpmvs_get. */
+int mpmvs_run_get(mpmvs_ctx* ctx, const mpmvs_params* params, uint64_t seed, void* planes4, void* costs, void* geom_costs);
 /* one kernel of Run(), for parity tests; launch_id selects the RNG stream the
  * way Run() numbers its launches (0 = InitializeScore, then in launch order) */
 int mpmvs_step(mpmvs_ctx* ctx, const mpmvs_params* params, uint64_t seed, int kind, int iter, int scale,

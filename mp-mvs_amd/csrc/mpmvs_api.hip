@@ -42,6 +42,8 @@ static_assert(sizeof(mpmvs_params) == 56, "PatchMatchParams layout");
 struct mpmvs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // mpmvs_run_get: the cost maps go to the host while the median filter still runs
+    hipEvent_t costs_final = nullptr;
     int n_img = 0, W = 0, H = 0;
     std::vector<mpmvs_camera> cams;
     ProblemDev hP;               // host mirror
@@ -418,6 +420,8 @@ void mpmvs_destroy(mpmvs_ctx* c) {
     free_views(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     if (c->dP) (void)hipFree(c->dP);
+    if (c->costs_final) (void)hipEventDestroy(c->costs_final);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -766,7 +770,10 @@ static int finish(mpmvs_ctx* c) {
 
 extern "C" {
 
-int mpmvs_run(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed) {
+// Run() (ref .cu:1188-1254).  With output pointers the device-to-host copies that end the reference's Run() (:1246-1251) are
+// part of the call: costs (and geometric costs) are final after the last update launch, so they travel on a second stream
+// while GetDepthandNormal and the median filter still run; the planes follow on the main stream.
+static int run_impl(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, void* planes4, void* costs, void* geom) {
     if (!c || !p) return -1;
     HIPCHK(c, enter_device(c->device));
     int rc = check_ready(c, p);
@@ -789,10 +796,29 @@ int mpmvs_run(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed) {
                 if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_RED, i, s, launch++))) return rc;
             }
     }
+    const size_t wh = (size_t)c->W * c->H;
+    const bool early = costs || geom;
+    if (early) {
+        if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        if (!c->costs_final) HIPCHK(c, hipEventCreateWithFlags(&c->costs_final, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->costs_final, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->costs_final, 0));
+        if (costs) HIPCHK(c, hipMemcpyAsync(costs, c->S.costs, wh * 4, hipMemcpyDeviceToHost, c->copy_stream));
+        if (geom) HIPCHK(c, hipMemcpyAsync(geom, c->S.geom, wh * 4, hipMemcpyDeviceToHost, c->copy_stream));
+    }
     if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_DEPTH_NORMAL, 0, 0, launch++))) return rc;
     if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_FILTER_BLACK, 0, 0, launch++))) return rc;
     if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_FILTER_RED, 0, 0, launch++))) return rc;
+    if (planes4) HIPCHK(c, hipMemcpyAsync(planes4, c->S.planes, wh * 16, hipMemcpyDeviceToHost, c->stream));
+    if (early) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     return finish(c);
+}
+
+int mpmvs_run(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed) { return run_impl(c, p, seed, nullptr, nullptr, nullptr); }
+
+int mpmvs_run_get(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, void* planes4, void* costs, void* geom) {
+    if (geom && (!p || !p->geom_consistency)) return c ? fail(c, -1, "geometric costs requested from a Run() without geometric consistency") : -1;
+    return run_impl(c, p, seed, planes4, costs, geom);
 }
 
 int mpmvs_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int kind, int iter, int scale, uint32_t launch_id) {

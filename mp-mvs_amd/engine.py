@@ -6,6 +6,8 @@ visible, creating a context raises.
 import ctypes as C
 import os
 
+import numpy as np
+
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -14,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmpmvs_hip.so")
 # entry points of include/mpmvs.h beyond the set shared with the test oracle
 _P = C.c_void_p
 _EXTRA = {
+    "run_get": (C.c_int, [_P, C.POINTER(_abi.PatchMatchParams), C.c_uint64, _P, _P, _P]),
     "verify_rcp": (C.c_int, [C.POINTER(C.c_ulonglong)]),
     "device_count": (C.c_int, []),
     "set_src_depths_device": (C.c_int, [_P, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -70,6 +73,13 @@ class HipPatchMatch(_abi.PatchMatchHandle):
             raise RuntimeError("mpmvs_create failed: " + (msg.decode() if msg else "unknown"))
         super().__init__(fns, ctx)
         self.device = int(device)
+
+    def run_into(self, params, seed, planes, costs, geom=None):
+        """Run() with the device-to-host copies that end it in the reference (mpmvs_run_get): the cost maps travel while the
+        median filter still runs; arrays as for get_into (pinned memory keeps the copies asynchronous)"""
+        assert planes.shape == (self.H, self.W, 4) and costs.shape == (self.H, self.W) and planes.dtype == np.float32 and costs.dtype == np.float32
+        self._chk(self._f["run_get"](self._ctx, C.byref(params), int(seed), planes.ctypes.data, costs.ctypes.data,
+                                     geom.ctypes.data if geom is not None else None), "run_get")
 
     def set_texture_format(self, force_fp32):
         """call before set_views; True keeps the fp32 texture format even for 8-bit exact images"""

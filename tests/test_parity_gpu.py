@@ -75,6 +75,31 @@ def test_math_bit_exact(pm, oracle, engine, fn, lo, hi):
     assert_same(f"math fn {fn}", got, want)
 
 
+def test_run_get_equals_run_then_get(pm, oracle, engine):
+    """mpmvs_run_get (Run() with its device-to-host copies, the cost maps overlapped with the median filter) returns what
+    mpmvs_run + mpmvs_get return, in photometric and in geometric mode"""
+    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, 96, 64, 3)
+    H, W = 64, 96
+    gpu.run(prm, SEED)
+    p0, c0 = gpu.get()
+    p1, c1 = np.empty((H, W, 4), np.float32), np.empty((H, W), np.float32)
+    gpu.run_into(prm, SEED, p1, c1)
+    assert_same("planes", p1, p0)
+    assert_same("costs", c1, c0)
+    rng = np.random.default_rng(3)
+    gpu.set_src_depths([sc.views[i].gt_depth * (1.0 + 0.01 * rng.standard_normal((H, W))).astype(np.float32) for i in (1, 2, 3)])
+    prm.geom_consistency, prm.max_iterations = True, 2
+    gpu.set_state(p0, c0)
+    gpu.run(prm, SEED + 1)
+    pa, ca, ga = gpu.get(geom=True)
+    pb, cb, gb = np.empty((H, W, 4), np.float32), np.empty((H, W), np.float32), np.empty((H, W), np.float32)
+    gpu.set_state(p0, c0)
+    gpu.run_into(prm, SEED + 1, pb, cb, gb)
+    assert_same("planes (geom)", pb, pa)
+    assert_same("costs (geom)", cb, ca)
+    assert_same("geom costs", gb, ga)
+
+
 def test_reciprocal_exhaustive(engine):
     """the kernels' reciprocal (hardware seed + two Newton steps) equals the IEEE quotient the oracle computes for EVERY float
     whose reciprocal is normal, and follows the oracle's rule everywhere else: all 2^32 bit patterns, checked on the device"""
