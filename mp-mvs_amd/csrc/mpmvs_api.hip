@@ -49,8 +49,7 @@ struct mpmvs_ctx {
     ProblemDev hP;               // host mirror
     ProblemDev* dP = nullptr;    // device copy
     float* d_ref = nullptr;
-    // the quad-packed source textures of all views live in ONE allocation (a single buffer resource can then address
-    // every view: the cooperative kernels sample a different view per lane); d_src / d_src8 point into it
+    // the quad-packed source textures of all views live in ONE allocation; d_src / d_src8 point into it
     void* d_tex_all = nullptr;
     std::vector<float*> d_src;      // fp32 format: w x h float4 texels per view
     std::vector<uint32_t*> d_src8;  // u8 format (every image 8-bit exact): w x h dwords per view

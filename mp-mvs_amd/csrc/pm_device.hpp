@@ -571,8 +571,8 @@ PM_DEV void plane_to_m(const ProblemDev& P, const float4 pl, float& m0, float& m
 }
 
 // ref .cu:325-414 ComputeBilateralNCC for one (hypothesis, source view), given the homography H = A - b m^T of the
-// pair, the texture handle of the view (wave-uniform SrcTex / SrcTex8, or per-lane LaneTex) and the LDS weight records of
-// the pixel (rw.lw[rec * LWSTRIDE]).
+// pair, the texture handle of the view (wave-uniform SrcTex / SrcTex8) and the LDS weight records of the pixel
+// (rw.lw[rec * LWSTRIDE]).
 template <bool U8, int LWSTRIDE, int SCALE, class TEX>
 PM_DEV float ncc_core(const TEX& tex, float wf, float hf, float H0, float H1, float H2, float H3, float H4, float H5, float H6, float H7, float H8,
                       const RefWin& rw, int px, int py) {

@@ -54,10 +54,10 @@ __device__ constexpr Off kDirs[8][12] = {
 __device__ constexpr int kNumDirs[8] = {12, 12, 12, 12, 10, 10, 10, 10};
 
 // Wave shape of the checkerboard launches: PM_WAVE_ROWS rows of 64/PM_WAVE_ROWS same-colour pixels; a 256-thread block
-// stacks its 4 waves vertically.  Compact 2-D patches reuse more L1 lines between taps than flat rows, and the wider the
-// texel the taller the best patch.  Measured per update launch, cfg 1 (round 2, quad-difference textures): fp16 texels
-// (8 bytes) 2 / 4 / 8 / 16 rows: 4.00 / 3.66 / 3.50 / 3.45 ms; fp32 texels (16 bytes) 4 / 8 / 16 / 32 rows: 4.72 / 4.47 /
-// 4.57 / 5.90 ms.  (Round 1, 4-byte u8 quads: 4 rows 3.85, 8 rows 3.89, 2 rows 3.98, 16 rows 4.84.)
+// stacks its 4 waves vertically.  Compact 2-D patches reuse more L1 lines between taps than flat rows.  Measured per update
+// launch, cfg 1, view-major order (round 2): fp16 texels (8 bytes) 8 / 16 / 32 rows: 3.37 / 3.40 / 4.01 ms; fp32 texels (16 bytes)
+// 4 / 8 / 16 rows: 4.18 / 3.97 / 4.04 ms.  (Slot-major order, mid round 2: fp16 2 / 4 / 8 / 16 rows 4.00 / 3.66 / 3.50 / 3.45 ms.
+// Round 1, 4-byte u8 quads: 4 rows 3.85, 8 rows 3.89, 2 rows 3.98, 16 rows 4.84.)
 #ifndef PM_WAVE_ROWS
 #define PM_WAVE_ROWS 8
 #endif
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
     for (int v = 0; v < MAXV; ++v) view_w[v] = 0.0f;
     const float thr = 0.8f * d_exp((float)(a.iter * a.iter) / (-90.0f));
 
-    // the pixel's current plane is read where it is needed (slots 8 and 9) instead of being carried through phase A
+    // the pixel's current plane is read where it is needed (phase B) instead of being carried through phase A
     const float depth_sigma = (a.depth_max - a.depth_min) / 64.0f;
     const float two_ds2 = (2.0f * depth_sigma) * depth_sigma;
     const float angle_sigma = 0.08726646f;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
     // 0 = current, 1 = random, 2 = perturbed.
     float park_n[9];
     float park_d[3];
-    float final_costs[8];  // written after phase A, read again only after the evaluation of slot 8: parked as well
+    float final_costs[8];  // written after phase A, read again only after the evaluation of the current plane: parked as well
     if (kPark) {
         keep_in_memory(park_n);
         keep_in_memory(park_d);
