@@ -125,7 +125,11 @@ def measured_traffic_bytes():
             elif kern == "k_update" and (t.startswith("FETCH_SIZE") or t.startswith("WRITE_SIZE")):
                 vals[t.split()[0]] = float(t.split("avg=")[1])
         if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-            best = (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0   # last file in name order = latest round
+            # last file in name order = latest round.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 128-byte requests at 64
+            # bytes (exactly half for wide coalesced streaming reads, to be doubled), other access widths are uncalibrated: this
+            # kernel's HBM reads are L2 misses of 8 / 16-byte gathers plus scratch refills, so the bytes lie between the raw sum
+            # (`traffic`) and the sum with FETCH_SIZE doubled (`traffic_if_fetch_doubled`)
+            best = ((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0)
     return best
 
 
@@ -476,7 +480,8 @@ def main():
                 "note": "achieved = SURVEY 8d's ALGORITHMIC flop per launch (14 hypotheses x 8 views x 2144 flop per pixel of one colour) / measured launch time; the "
                         "kernel executes roughly half of that (bilateral weights and reference moments once per pixel, homography as 9 fmas, one reciprocal per six taps, "
                         "zero-weight views skipped): it is an algorithmic-equivalent rate, not the VALU utilisation (that is in profiles/: SQ_ACTIVE_INST_VALU)",
-                "traffic": measured_traffic_bytes(),
+                "traffic": (measured_traffic_bytes() or (None, None))[0],
+                "traffic_if_fetch_doubled": (measured_traffic_bytes() or (None, None))[1],
                 "avg_launch_ms": round(upd_avg_ms, 4),
                 "launches_timed": upd_n,
                 "algorithmic_flop_per_launch": flops_per_launch,
