@@ -634,6 +634,46 @@ __global__ __launch_bounds__(256) void k_depth_normal(const ProblemDev* __restri
 // ---------------------------------------------------------------------------
 // Black/RedPixelFilter = CheckerboardFilter, ref .cu:1036-1174
 // ---------------------------------------------------------------------------
+// Median of 21 by min / max elimination in registers: of 12 values the smallest and the largest cannot be the median of all
+// 21, they go and the next value comes in; after nine such rounds three values are left and their middle one is the median.
+// All indices are compile-time constants (the array lives in registers); every step is a compare-exchange that keeps the
+// multiset intact.  Valid for values that are totally ordered by `<` (finite, one sign of zero): the caller checks.
+template <int K>
+PM_DEV void min_to_front_max_to_back(float (&v)[21]) {
+    constexpr int half = K / 2;
+#pragma unroll
+    for (int i = 0; i < half; ++i) {  // lows into the front half, highs into the back half
+        const float a = v[i], b = v[K - 1 - i];
+        v[i] = __builtin_fminf(a, b);
+        v[K - 1 - i] = __builtin_fmaxf(a, b);
+    }
+    constexpr int front_end = (K + 1) / 2;  // the middle value of an odd K may be the minimum as well as the maximum
+#pragma unroll
+    for (int i = 1; i < front_end; ++i) {
+        const float a = v[0], b = v[i];
+        v[0] = __builtin_fminf(a, b);
+        v[i] = __builtin_fmaxf(a, b);
+    }
+#pragma unroll
+    for (int i = half; i < K - 1; ++i) {
+        const float a = v[i], b = v[K - 1];
+        v[i] = __builtin_fminf(a, b);
+        v[K - 1] = __builtin_fmaxf(a, b);
+    }
+}
+template <int K>
+PM_DEV float median21_rounds(float (&v)[21], float& lowest) {
+    min_to_front_max_to_back<K>(v);
+    lowest = __builtin_fminf(lowest, v[0]);
+    if constexpr (K == 3) {
+        return v[1];
+    } else {
+        // drop v[0] and v[K-1]: the next unseen value (index 12 + (12 - K)) replaces v[0], the value before the maximum closes the gap
+        v[0] = v[12 + (12 - K)];
+        return median21_rounds<K - 1>(v, lowest);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_filter(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
     const ProblemDev& P = *Pp;
     int x, y, x0, y0;
@@ -641,6 +681,26 @@ __global__ __launch_bounds__(256) void k_filter(const ProblemDev* __restrict__ P
     const int W = P.W, Hh = P.H;
     const int ctr = y * W + x;
     if (S.costs[ctr] < 0.001f) return;
+    if (x > 4 && x < W - 5 && y > 4 && y < Hh - 5) {
+        // interior pixel: all 21 values exist (the order of the taps below is the reference's, it does not matter for a median)
+        float v[21];
+        constexpr int dx[21] = {0, 0, 0, 0, 0, 0, 0, -1, -3, -5, 1, 3, 5, 2, 2, -2, -2, -1, 1, -1, 1};
+        constexpr int dy[21] = {0, -1, -3, -5, 1, 3, 5, 0, 0, 0, 0, 0, 0, -1, 1, -1, 1, -2, -2, 2, 2};
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 21; ++i) {
+            v[i] = S.planes[ctr + dy[i] * W + dx[i]].w;
+            sum += v[i];
+        }
+        float lowest = v[0];
+        const float med = median21_rounds<12>(v, lowest);
+        // `<` orders finite positive depths totally, so the selection above found what the insertion sort below finds; anything
+        // else (a NaN or infinite depth shows in the sum, a zero or negative one in the minimum) takes the general path
+        if (lowest > 0.0f && sum < 3.0e38f) {
+            S.planes[ctr].w = med;
+            return;
+        }
+    }
     float f[21];
     int n = 0;
 #define PM_TAP(cond, off) \
