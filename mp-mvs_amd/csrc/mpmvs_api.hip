@@ -667,6 +667,17 @@ static void launch_update(mpmvs_ctx* c, const LaunchArgs& a) {
         launch_update2<GEOM, PRIOR, false>(c, a);
 }
 
+// the spatial half of the bilateral weight exponent (ref .cu:318-323) of the 36 window taps at `scale`, [column][row]
+static void fill_spatial_terms(LaunchArgs& a, int scale) {
+    const int step = 2 << scale, radius = 5 * step / 2;
+    for (int col = 0; col < 6; ++col)
+        for (int row = 0; row < 6; ++row) {
+            const int dx = col * step - radius, dy = row * step - radius;
+            const float sd = std::sqrt((float)dx * (float)dx + (float)dy * (float)dy);
+            a.spatial[col * 6 + row] = (-sd) / a.two_ss;
+        }
+}
+
 static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int kind, int iter, int scale, uint32_t launch) {
     if (scale < 0 || scale > 2) return fail(c, -3, "scale must be 0..2");
     if ((kind == MPMVS_KIND_BLACK || kind == MPMVS_KIND_RED) && scale != 0 && (p->geom_consistency || p->planar_prior))
@@ -683,6 +694,7 @@ static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int 
     a.depth_max = p->depth_max;
     a.two_ss = (2.0f * p->sigma_spatial) * p->sigma_spatial;
     a.two_sc = (2.0f * p->sigma_color) * p->sigma_color;
+    fill_spatial_terms(a, scale);
     a.init_random = (!p->geom_consistency && !p->planar_prior) ? 1 : 0;
     a.use_prior = p->planar_prior ? 1 : 0;
 
@@ -878,6 +890,7 @@ static int eval_ncc_impl(mpmvs_ctx* c, const mpmvs_params* p, const void* planes
     a.scale = scale;
     a.two_ss = (2.0f * p->sigma_spatial) * p->sigma_spatial;
     a.two_sc = (2.0f * p->sigma_color) * p->sigma_color;
+    fill_spatial_terms(a, scale);
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     HIPCHK(c, hipEventRecord(e0, c->stream));
     {

@@ -355,7 +355,7 @@ PM_DEV void load_ref_tile(const ProblemDev& P, float* tile, int x0, int y0, int 
 // weights of one pixel -> LDS column `lw`.  tap(dx, dy) reads the reference image at the pixel + (dx, dy): from the block's
 // LDS tile, or from the apron-padded image in global memory (see Win).
 template <int SCALE, class TAP>
-PM_DEV void ref_window(float4* lw, TAP tap, float two_ss, float two_sc, RefWin& rw) {
+PM_DEV void ref_window(float4* lw, TAP tap, const float (&spatial)[36], float two_sc, RefWin& rw) {
     constexpr int step = 2 << SCALE, radius = 5 * step / 2;
     const float rc = tap(0, 0);
     float sw = 0.0f, swr = 0.0f, swrr = 0.0f;
@@ -367,8 +367,7 @@ PM_DEV void ref_window(float4* lw, TAP tap, float two_ss, float two_sc, RefWin& 
         for (int b = 0; b < 6; ++b) {
             const int dx = a * step - radius, dy = b * step - radius;
             const float r = tap(dx, dy);
-            const float sd = __builtin_sqrtf((float)dx * (float)dx + (float)dy * (float)dy);
-            const float e = (-sd) / two_ss - __builtin_fabsf(r - rc) / two_sc;
+            const float e = spatial[a * 6 + b] - __builtin_fabsf(r - rc) / two_sc;  // ref .cu:318-323
             const float w = d_exp(e);
             const float wr = w * r;
             wv[b] = w;
@@ -392,7 +391,7 @@ PM_DEV void ref_window(float4* lw, TAP tap, float two_ss, float two_sc, RefWin& 
 
 // stages the block's reference tile if it is to live in LDS and fills the pixel's weight column
 template <int SCALE, int BW, int BH>
-PM_DEV void ref_window_of_pixel(const ProblemDev& P, int x, int y, int x0, int y0, bool valid, float two_ss, float two_sc, RefWin& rw) {
+PM_DEV void ref_window_of_pixel(const ProblemDev& P, int x, int y, int x0, int y0, bool valid, const float (&spatial)[36], float two_sc, RefWin& rw) {
     typedef Win<SCALE, BW, BH> Wn;
     float4* lw = (float4*)pm_lds + threadIdx.x;
     if constexpr (Wn::tile_in_lds) {
@@ -400,12 +399,12 @@ PM_DEV void ref_window_of_pixel(const ProblemDev& P, int x, int y, int x0, int y
         __syncthreads();
         if (!valid) return;
         const int ctr = kLdsWeightFloats + (y - y0 + Wn::radius) * Wn::pitch + (x - x0 + Wn::radius);
-        ref_window<SCALE>(lw, [&](int dx, int dy) { return pm_lds[ctr + dy * Wn::pitch + dx]; }, two_ss, two_sc, rw);
+        ref_window<SCALE>(lw, [&](int dx, int dy) { return pm_lds[ctr + dy * Wn::pitch + dx]; }, spatial, two_sc, rw);
     } else {
         if (!valid) return;
         const float* ctr = P.ref_img + (long)y * P.ref_pitch + x;
         const int pitch = P.ref_pitch;
-        ref_window<SCALE>(lw, [&](int dx, int dy) { return ctr[dy * pitch + dx]; }, two_ss, two_sc, rw);
+        ref_window<SCALE>(lw, [&](int dx, int dy) { return ctr[dy * pitch + dx]; }, spatial, two_sc, rw);
     }
 }
 

@@ -34,6 +34,9 @@ struct LaunchArgs {
     int top_k;
     float depth_min, depth_max;
     float two_ss, two_sc;  // 2*sigma_spatial^2, 2*sigma_color^2
+    // -sqrt(dx^2 + dy^2) / two_ss of the 36 window taps [column][row] at this launch's scale: the same for every pixel, so the
+    // host computes it once per launch (the same fp32 square root and division the kernel used to do 36 times per pixel)
+    float spatial[36];
     int init_random;       // InitializeScore branch A (ref .cu:549)
     int use_prior;         // params.planar_prior
 };
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_init(const ProblemDe
     int x, y, x0, y0;
     const bool valid = dense_pixel(P, x, y, x0, y0);
     RefWin rw;
-    ref_window_of_pixel<SCALE, 16, 16>(P, x, y, x0, y0, valid, a.two_ss, a.two_sc, rw);
+    ref_window_of_pixel<SCALE, 16, 16>(P, x, y, x0, y0, valid, a.spatial, a.two_sc, rw);
     if (!valid) return;
     const int idx = y * P.W + x;
     const int V = P.V;
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
     int x, y, x0, y0;
     const bool valid = checker_pixel<U8>(P, a, x, y, x0, y0);
     RefWin rw;
-    ref_window_of_pixel<SCALE, kChkBlockW<U8>, kChkBlockH<U8>>(P, x, y, x0, y0, valid, a.two_ss, a.two_sc, rw);
+    ref_window_of_pixel<SCALE, kChkBlockW<U8>, kChkBlockH<U8>>(P, x, y, x0, y0, valid, a.spatial, a.two_sc, rw);
     if (!valid) return;
     const int W = P.W, Hh = P.H, V = P.V;
     const int idx = y * W + x;
@@ -786,7 +789,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_eval_ncc(const Probl
     int x, y, x0, y0;
     const bool valid = dense_pixel(P, x, y, x0, y0);
     RefWin rw;
-    ref_window_of_pixel<SCALE, 16, 16>(P, x, y, x0, y0, valid, a.two_ss, a.two_sc, rw);
+    ref_window_of_pixel<SCALE, 16, 16>(P, x, y, x0, y0, valid, a.spatial, a.two_sc, rw);
     if (!valid) return;
     const int idx = y * P.W + x;
     const long wh = (long)P.W * P.H;
