@@ -183,6 +183,37 @@ def test_delaunay_large_sets_parallel_and_serial_agree(hostlib, monkeypatch, W, 
             assert np.array_equal(ref, tris), f"{threads} threads"
 
 
+@pytest.mark.parametrize("kind", range(6))
+def test_delaunay_point_distributions(hostlib, monkeypatch, kind):
+    """uniform, near-vertical and near-horizontal bands, one cluster, a lattice-like pattern, heavy duplication: valid and
+    independent of the number of threads"""
+    rng = np.random.default_rng(100 + kind)
+    n = 9000
+    if kind == 0:
+        pts = rng.integers(0, 2000, size=(n, 2))
+    elif kind == 1:
+        pts = np.stack([rng.integers(0, 40, n) * 50 + rng.integers(0, 3, n), rng.integers(0, 3000, n)], -1)
+    elif kind == 2:
+        pts = np.stack([rng.integers(0, 3000, n), rng.integers(0, 30, n) * 70 + rng.integers(0, 2, n)], -1)
+    elif kind == 3:
+        pts = (rng.normal(size=(n, 2)) * 200 + 1000).astype(np.int64)
+    elif kind == 4:
+        pts = np.stack([np.arange(n) % 997, (np.arange(n) * 7) % 1013], -1)
+    else:
+        pts = rng.integers(0, 90, size=(n, 2))
+    pts = np.clip(pts, 0, 4095).astype(np.int32)
+    uniq = np.unique(pts, axis=0)
+    ref = None
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("MPMVS_HOST_THREADS", threads)
+        tris = np.array(hostlib.delaunay(4096, 4096, pts))
+        if ref is None:
+            ref = tris
+            _check_triangulation(uniq, tris)
+        else:
+            assert np.array_equal(ref, tris), f"{threads} threads"
+
+
 def test_delaunay_full_lattice_parallel(hostlib, monkeypatch):
     """every quadruple of neighbours cocircular, every row and column collinear, 8 threads"""
     monkeypatch.setenv("MPMVS_HOST_THREADS", "8")
