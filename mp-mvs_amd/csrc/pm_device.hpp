@@ -310,9 +310,9 @@ PM_DEV float4 perturbed_normal(const ProblemDev& P, int px, int py, const float4
 //   * the 36 bilateral weights w and products w*r of a pixel live in a per-thread LDS column of 18 float4 ([tap pair][thread],
 //     one conflict-free ds_read_b128 per tap pair), leaving the VGPRs to the gather pipeline of the NCC loop.
 // LDS layout (one array): [18 * kBlockThreads float4][tile floats].
-// Round 2 tried 4-byte records (w only, w*r recomputed from the tile in every evaluation) so that three blocks fit a CU: the
-// NCC core gains ~5 % from the third wave per SIMD but pays 4 % for the extra LDS reads and products, and the update kernel
-// squeezed into 168 registers loses more than that.
+// Round 2 tried 4-byte records (w only, w*r recomputed from the tile in every evaluation) so that three blocks fit a CU, both
+// for the whole update kernel (squeezed into 168 registers: slower) and for its phase A as a kernel of its own (fits easily:
+// exactly as fast as with two waves per SIMD): the third wave buys this workload nothing.
 // ---------------------------------------------------------------------------
 constexpr int kBlockThreads = 256;
 extern __shared__ float pm_lds[];  // dynamic LDS of the NCC kernels
