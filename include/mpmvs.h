@@ -145,8 +145,11 @@ int mpmvs_get_prior(mpmvs_ctx* ctx, void* prior_planes4, void* mask_u32);
  * geom_consistency before the prior Run(), src/PatchMatch.cpp:535). */
 int mpmvs_run(mpmvs_ctx* ctx, const mpmvs_params* params, uint64_t seed);
 /* Run() together with the device-to-host copies that end it in the reference (src/PatchMatch.cu:1246-1251): planes (float4 =
- * world normal + depth), costs and -- geometric consistency only -- geometric costs into host buffers of W*H elements (each
- * may be NULL; pinned memory makes the copies asynchronous).  The cost maps are final after the last update launch and
+ * world normal + depth), costs and geometric costs into host buffers of W*H elements (each may be NULL; pinned memory makes
+ * the copies asynchronous).  The reference copies hostGeomCosts whenever params.geomPlanarPrior is set (:1248) -- also in
+ * the planar-prior re-run of a geometric pass, where the flag is still set (src/PatchMatch.cpp:535,655-665) and the map is the
+ * one the geometric Run() left on the device -- so a caller passes `params.geomPlanarPrior ? hostGeomCosts : NULL` and any
+ * Run() accepts the buffer: it receives what cudaGeomCosts holds.  The cost maps are final after the last update launch and
  * travel while the median filter still runs.  Same results as mpmvs_run followed by mpmvs_get. */
 int mpmvs_run_get(mpmvs_ctx* ctx, const mpmvs_params* params, uint64_t seed, void* planes4, void* costs, void* geom_costs);
 /* one kernel of Run(), for parity tests; launch_id selects the RNG stream the
@@ -194,7 +197,7 @@ int mpmvs_rng(uint64_t seed, uint32_t pix, uint32_t launch_id, int n, void* out)
  * pixel, world frame), colors[k] (8-bit, color_channels = 3: interleaved B,G,R as the
  * reference's cv::Vec3b image, :324; or 1: grey, replicated), estimate[k] (0 = skip),
  * and the view list src_ids[src_off[k] .. src_off[k+1]) whose first entry is k itself
- * (Scene::srcID).  sky may be NULL, or hold per image NULL or an 8-bit mask of the map's
+ * (Scene::srcID); a list that names a view twice, or image k among its own sources, is rejected (-2).  sky may be NULL, or hold per image NULL or an 8-bit mask of the map's
  * size: pixels with sky > 0 are masked when their image is fused (:385-388).
  * Outputs per image: out_valid (1 where a fused point was produced), out_points9
  * (x y z nx ny nz c0 c1 c2 per pixel, colour in the input channel order), out_masks

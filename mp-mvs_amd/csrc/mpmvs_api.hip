@@ -405,6 +405,8 @@ mpmvs_ctx* mpmvs_create(int device) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc(&c->dP, sizeof(ProblemDev))) != hipSuccess) {
         g_create_err = std::string("context setup: ") + hipGetErrorString(e);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        (void)hipGetLastError();
         delete c;
         return nullptr;
     }
@@ -427,13 +429,7 @@ void mpmvs_destroy(mpmvs_ctx* c) {
 
 const char* mpmvs_last_error(const mpmvs_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
-int mpmvs_set_views(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* const* images, const size_t* pitch_bytes) {
-    if (!c) return -1;
-    HIPCHK(c, enter_device(c->device));
-    if (n < 2 || n - 1 > MPMVS_MAX_SRC_VIEWS) return fail(c, -1, "need 2..33 views");
-    for (int i = 0; i < n; ++i)
-        if (cams[i].width <= 0 || cams[i].height <= 0 || !images[i]) return fail(c, -2, "bad image size or null image");
-    free_views(c);
+static int set_views_impl(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* const* images, const size_t* pitch_bytes) {
     c->n_img = n;
     c->cams.assign(cams, cams + n);
     c->W = cams[0].width;
@@ -452,7 +448,9 @@ int mpmvs_set_views(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* 
     std::vector<std::vector<unsigned char>> src8;
     bool exact = !c->force_f32 && convert_sources_u8(n, cams, images, pitch_bytes, src8);
     c->all_u8 = exact;
-    // one allocation for the textures of all views, each 256-byte aligned; a buffer resource addresses 32-bit offsets
+    // one allocation for the textures of all views, each 256-byte aligned.  Every view is addressed through its own buffer
+    // resource (base = the view's first texel, 32-bit offsets inside it), so only a single view is limited to 4 GB
+    // (checked by the caller), not the allocation: 32 views of 3200 x 3200 fp32 texels are 5.2 GB.
     const size_t texel = exact ? 8 : 16;
     std::vector<size_t> tex_off(n, 0);
     size_t tex_total = 0;
@@ -460,27 +458,22 @@ int mpmvs_set_views(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* 
         tex_off[v] = tex_total;
         tex_total += ((size_t)cams[v].width * cams[v].height * texel + 255) & ~(size_t)255;
     }
-    if (tex_total >= (1ull << 32)) return fail(c, -3, "source textures exceed 4 GB in total");
     HIPCHK(c, pool_malloc(&c->d_tex_all, tex_total));
-    c->hP.tex_all = c->d_tex_all;
-    c->hP.tex_all_bytes = (uint32_t)tex_total;
     if (exact) c->d_src8.assign(n - 1, nullptr); else c->d_src.assign(n - 1, nullptr);
-    unsigned char* d_stage = nullptr;
+    PoolBuf d_stage;  // back to the pool on every return path; the callers synchronise the stream first
     if (exact) {
         size_t biggest = 0;
         for (int v = 1; v < n; ++v) biggest = std::max(biggest, (size_t)cams[v].width * cams[v].height);
-        HIPCHK(c, pool_malloc(&d_stage, biggest));
+        HIPCHK(c, d_stage.alloc(biggest));
     }
     for (int v = 1; v < n; ++v) {
         const int w = cams[v].width, h = cams[v].height;
         const size_t pitch = pitch_bytes ? pitch_bytes[v] : (size_t)w * 4;
         ViewDev& o = c->hP.views[v - 1];
-        o.tex_base = (uint32_t)tex_off[v];
         if (exact) {
             c->d_src8[v - 1] = (uint32_t*)((char*)c->d_tex_all + tex_off[v]);
-            if ((rc = upload_quads_u8(c, src8[v - 1].data(), d_stage, w, h, c->d_src8[v - 1]))) {
+            if ((rc = upload_quads_u8(c, src8[v - 1].data(), d_stage.as<unsigned char>(), w, h, c->d_src8[v - 1]))) {
                 (void)hipStreamSynchronize(c->stream);
-                (void)pool_free(d_stage);
                 return rc;
             }
             o.pitch8 = w;
@@ -493,16 +486,37 @@ int mpmvs_set_views(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* 
         }
     }
     const size_t wh = (size_t)c->W * c->H;
-    HIPCHK(c, pool_malloc(&c->S.planes, wh * 16));
-    HIPCHK(c, pool_malloc(&c->S.costs, wh * 4));
-    HIPCHK(c, pool_malloc(&c->S.sel, wh * 4));
-    HIPCHK(c, pool_malloc(&c->S.geom, wh * 4));
-    HIPCHK(c, hipMemsetAsync(c->S.planes, 0, wh * 16, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->S.costs, 0, wh * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->S.sel, 0, wh * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->S.geom, 0, wh * 4, c->stream));
-    rc = upload_problem(c);  // synchronises the stream: the staged 8-bit copies are complete
-    if (d_stage) (void)pool_free(d_stage);
+    rc = -100;
+    if (pool_malloc(&c->S.planes, wh * 16) == hipSuccess && pool_malloc(&c->S.costs, wh * 4) == hipSuccess &&
+        pool_malloc(&c->S.sel, wh * 4) == hipSuccess && pool_malloc(&c->S.geom, wh * 4) == hipSuccess &&
+        hipMemsetAsync(c->S.planes, 0, wh * 16, c->stream) == hipSuccess && hipMemsetAsync(c->S.costs, 0, wh * 4, c->stream) == hipSuccess &&
+        hipMemsetAsync(c->S.sel, 0, wh * 4, c->stream) == hipSuccess && hipMemsetAsync(c->S.geom, 0, wh * 4, c->stream) == hipSuccess)
+        rc = 0;
+    if (rc) c->err = "allocation of the per-pixel state failed";
+    const int rc_up = upload_problem(c);  // synchronises the stream (also on the failure path): the staged 8-bit copies are complete
+    return rc ? rc : rc_up;
+}
+
+int mpmvs_set_views(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* const* images, const size_t* pitch_bytes) {
+    if (!c) return -1;
+    HIPCHK(c, enter_device(c->device));
+    if (n < 2 || n - 1 > MPMVS_MAX_SRC_VIEWS) return fail(c, -1, "need 2..33 views");
+    for (int i = 0; i < n; ++i) {
+        if (cams[i].width <= 0 || cams[i].height <= 0 || !images[i]) return fail(c, -2, "bad image size or null image");
+        // texel indices are formed with a 24-bit multiply (texel_index, pm_device.hpp) and offsets inside a view are 32 bits
+        if (cams[i].width >= (1 << 24) || cams[i].height >= (1 << 24) || (size_t)cams[i].width * cams[i].height * 16 >= (1ull << 32))
+            return fail(c, -3, "image too large (a view's texture must stay below 4 GB)");
+    }
+    free_views(c);
+    const int rc = set_views_impl(c, n, cams, images, pitch_bytes);
+    if (rc) {  // no half-built Problem is left behind: the context is as after mpmvs_create
+        const std::string why = c->err;
+        free_views(c);
+        c->n_img = c->W = c->H = 0;
+        c->cams.clear();
+        std::memset(&c->hP, 0, sizeof(ProblemDev));
+        c->err = why;
+    }
     return rc;
 }
 
@@ -782,15 +796,25 @@ extern "C" {
 // Run() (ref .cu:1188-1254).  With output pointers the device-to-host copies that end the reference's Run() (:1246-1251) are
 // part of the call: costs (and geometric costs) are final after the last update launch, so they travel on a second stream
 // while GetDepthandNormal and the median filter still run; the planes follow on the main stream.
-static int run_impl(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, void* planes4, void* costs, void* geom) {
-    if (!c || !p) return -1;
-    HIPCHK(c, enter_device(c->device));
-    int rc = check_ready(c, p);
-    if (rc) return rc;
-    for (int k = 0; k < 6; ++k) {
-        c->k_ms[k] = 0.0f;
-        c->k_cnt[k] = 0;
+// Everything a failed Run() may have left behind: launches and copies into caller buffers still in flight on either stream
+// (the caller may free its buffers once the call has returned), and profiling events that would otherwise be booked on the
+// next call.  Returns `rc` unchanged.
+static int abandon_run(mpmvs_ctx* c, int rc) {
+    const std::string why = c->err;
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& pe : c->pending) {
+        c->event_pool.push_back(pe.second.first);
+        c->event_pool.push_back(pe.second.second);
     }
+    c->pending.clear();
+    (void)hipGetLastError();
+    c->err = why;
+    return rc;
+}
+
+static int enqueue_run(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, void* planes4, void* costs, void* geom) {
+    int rc;
     uint32_t launch = 0;
     if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_INIT, 0, p->max_scale, launch++))) return rc;
     if (p->geom_consistency || p->planar_prior) {
@@ -823,10 +847,30 @@ static int run_impl(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, void* pl
     return finish(c);
 }
 
+// Run() (ref .cu:1188-1254).  With output pointers the device-to-host copies that end the reference's Run() (:1246-1251) are
+// part of the call: costs (and geometric costs) are final after the last update launch, so they travel on a second stream
+// while GetDepthandNormal and the median filter still run; the planes follow on the main stream.
+static int run_impl(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, void* planes4, void* costs, void* geom) {
+    if (!c || !p) return -1;
+    HIPCHK(c, enter_device(c->device));
+    int rc = check_ready(c, p);
+    if (rc) return rc;
+    for (int k = 0; k < 6; ++k) {
+        c->k_ms[k] = 0.0f;
+        c->k_cnt[k] = 0;
+    }
+    rc = enqueue_run(c, p, seed, planes4, costs, geom);
+    return rc ? abandon_run(c, rc) : 0;
+}
+
 int mpmvs_run(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed) { return run_impl(c, p, seed, nullptr, nullptr, nullptr); }
 
+// The geometric-cost buffer follows the reference's rule (ref .cu:1248): Run() copies cudaGeomCosts whenever
+// params.geomPlanarPrior is set, whatever the mode of THIS Run() -- the flag survives SetGeomConsistencyParams(false, true)
+// (ref .cpp:655-665), so the planar-prior re-run of a geometric pass (ref .cpp:535,604) copies the map its geometric Run()
+// left behind (the prior kernels do not write it).  Any Run() may therefore be given a buffer; it receives what the device
+// holds (zeros before the first geometric Run() of the context).
 int mpmvs_run_get(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, void* planes4, void* costs, void* geom) {
-    if (geom && (!p || !p->geom_consistency)) return c ? fail(c, -1, "geometric costs requested from a Run() without geometric consistency") : -1;
     return run_impl(c, p, seed, planes4, costs, geom);
 }
 
@@ -835,8 +879,8 @@ int mpmvs_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int kind, int
     HIPCHK(c, enter_device(c->device));
     int rc = check_ready(c, p);
     if (rc) return rc;
-    if ((rc = enqueue_step(c, p, seed, kind, iter, scale, launch_id))) return rc;
-    return finish(c);
+    if ((rc = enqueue_step(c, p, seed, kind, iter, scale, launch_id)) || (rc = finish(c))) return abandon_run(c, rc);
+    return 0;
 }
 
 int mpmvs_get(mpmvs_ctx* c, void* planes4, void* costs, void* geom) {
@@ -1135,10 +1179,17 @@ static int fuse_impl(int device, int n, const mpmvs_camera* cams, const int* est
     // every view id is used as an index below (host vectors, FuseView table, masks): reject lists that name images that do
     // not exist before anything is launched (the reference looks ids up in a map, src/PatchMatch.cpp:306-312)
     if (!src_off || !src_ids || src_off[0] != 0) return -2;
+    // ... and lists that name a view twice or the image itself among its sources: the masks of a source are advanced once per
+    // slot (a view named twice would be swapped back and the reference-order fixpoint would never settle), and the reference
+    // masks the fused image's own pixels in place, which the per-image snapshot cannot express
     for (int i = 0; i < n; ++i) {
         if (src_off[i + 1] < src_off[i]) return -2;
-        for (int k = src_off[i]; k < src_off[i + 1]; ++k)
+        for (int k = src_off[i]; k < src_off[i + 1]; ++k) {
             if (src_ids[k] < 0 || src_ids[k] >= n) return -2;
+            if (k > src_off[i] && src_ids[k] == i) return -2;
+            for (int k2 = src_off[i]; k2 < k; ++k2)
+                if (src_ids[k2] == src_ids[k]) return -2;
+        }
     }
     // own stream: a fusion call must not stall the PatchMatch contexts other host threads drive on this device
     hipStream_t st = nullptr;
@@ -1286,7 +1337,7 @@ static int fuse_impl(int device, int n, const mpmvs_camera* cams, const int* est
                 for (int j = 1; j < num_ngb; ++j) std::swap(hv[src_ids[b + j]].tau, hv[src_ids[b + j]].tau_new);
                 if (hipMemcpyAsync(d_views, hv.data(), sizeof(FuseView) * n, hipMemcpyHostToDevice, st) != hipSuccess) { rc = -100; break; }
                 if (changed == 0) break;   // tau (now in .tau) reproduces itself: the sequential result
-                if (passes > npix) { rc = -3; break; }   // cannot happen: every pass fixes at least one more pixel
+                if (passes > npix || passes > 4096) { rc = -3; break; }   // every pass fixes at least one more pixel; measured <= 7 per image
             }
             g_fuse_passes_total += passes;
             g_fuse_passes_max = std::max(g_fuse_passes_max, passes);

@@ -43,7 +43,6 @@ struct ViewDev {
     const float* depth;  // dense source depth map (geometric consistency) or null
     int dw, dh;
     float dwm1, dhm1;
-    uint32_t tex_base;  // byte offset of this view's texture inside ProblemDev::tex_all
     CamDev cam;
 };
 
@@ -55,8 +54,6 @@ struct ProblemDev {
     int W, H, V;
     const float* ref_img;  // texel (0,0) of the reference image, apron kRefApron
     int ref_pitch;
-    const void* tex_all;     // the one allocation holding the quad-packed textures of all source views
-    uint32_t tex_all_bytes;
     ViewDev views[kMaxViews];
 };
 

@@ -1,10 +1,11 @@
 // pm_kernels.hpp -- the __global__ kernels of the PatchMatch hot path for gfx950.
 //
-// One thread owns one reference pixel (64-wide wavefront = 32x4 pixel patch of
-// one checkerboard colour, or an 8x8 patch for the all-pixel kernels), keeps
-// the 36 bilateral weight records of its window in LDS, and walks the 14
-// hypotheses of an update through ONE copy of the unrolled 36-tap NCC loop
-// ("slot loop"), so the hot code stays small in the instruction cache.
+// One thread owns one reference pixel.  A 64-wide wavefront is a 16x8 pixel patch of one checkerboard colour (8 lanes x 8
+// rows) in the update / filter launches and an 8x8 patch in the all-pixel launches; a block is four waves.  The 36 bilateral
+// weight records of the pixel's window live in LDS (written once per pixel and launch, read by every evaluation).
+// k_update walks its 14 hypotheses in two phases, each VIEW BY VIEW (the eight propagated candidates of a view back to back,
+// then the current plane, then the five refinement candidates of a view back to back), through inlined copies of the
+// unrolled 36-tap NCC loop (ncc_core, pm_device.hpp) -- five copies in the photometric kernel's ISA.
 // MFMA is not used: there is no dense contraction on this path.
 #pragma once
 

@@ -128,14 +128,19 @@ class PatchMatchCUDA {
     Scene* ref_scene = nullptr;     // Scenes[ID] of PatchMatchInit: owner of the device cache
     bool views_resident = false;    // the adopted context already holds this Problem's textures
     bool host_state_valid = false;  // hostPlaneHypotheses / hostCosts mirror the device state
+    bool deferred_fetch = false;    // Run() leaves its maps in HBM until the host first reads one (SetDeferredFetch)
     void check(int rc, const char* what);
-    void fetch_host_state();        // the device-to-host block of Run() (reference src/PatchMatch.cu:1246-1251), on first use
+    void fetch_host_state();        // the device-to-host block of Run() (reference src/PatchMatch.cu:1246-1251) when it was deferred
 
    public:
     ~PatchMatchCUDA();
     void SetDevice(int dev) { device = dev; }
     void SetSeed(uint64_t s) { seed = s; }
     void SetMaxScale(int s) { params.max_scale = s; }  // the reference has no setter
+    // Run() normally ends with the reference's device-to-host copies (src/PatchMatch.cu:1246-1251); with deferred fetch the maps
+    // are copied when GetPlaneHypothesis / GetCost / GetGeomCost is first called (the first Run() of a planar-prior Problem
+    // whose prior is built on the device then copies nothing)
+    void SetDeferredFetch(bool on) { deferred_fetch = on; }
     const PatchMatchParams& GetParams() const { return params; }
 
     void SetGeomConsistencyParams(bool geom_consistency, bool planar_prior);

@@ -276,17 +276,26 @@ void PatchMatchCUDA::CudaPlanarPriorInitialization(const std::vector<Triangle>& 
     check(mpmvs_prior_from_triangles(ctx, &params, tri_xy.data(), (int)(tri_xy.size() / 6)), "mpmvs_prior_from_triangles");
 }
 
-// reference src/PatchMatch.cu:1188-1254: the launches live behind mpmvs_run; the device-to-host copies that end the
-// reference's Run() (:1246-1251) are made when the host first asks for a value (fetch_host_state): between the two Run()
-// calls of a planar-prior Problem nothing has to leave HBM
+// reference src/PatchMatch.cu:1188-1254, exactly the stub of INTEGRATION.md section 2: the launches AND the device-to-host
+// copies that end the reference's Run() (:1246-1251) are one mpmvs_run_get call; hostGeomCosts travels whenever
+// params.geomPlanarPrior is set (:1248), which includes the planar-prior re-run of a geometric pass.
+// SetDeferredFetch(true) (not in the reference) turns the copies into a fetch on first host access: between the two Run()
+// calls of a planar-prior Problem whose prior is built on the device nothing has to leave HBM.
 void PatchMatchCUDA::Run() {
-    check(mpmvs_run(ctx, &params, seed), "mpmvs_run");
-    host_state_valid = false;
+    if (deferred_fetch) {
+        check(mpmvs_run(ctx, &params, seed), "mpmvs_run");
+        host_state_valid = false;
+        return;
+    }
+    if (params.geomPlanarPrior && hostGeomCosts.empty()) hostGeomCosts.assign(hostCosts.size(), 0.0f);
+    check(mpmvs_run_get(ctx, &params, seed, hostPlaneHypotheses.data(), hostCosts.data(), params.geomPlanarPrior ? hostGeomCosts.data() : nullptr),
+          "mpmvs_run_get");
+    host_state_valid = true;
 }
 void PatchMatchCUDA::fetch_host_state() {
     if (host_state_valid) return;
     if (hostGeomCosts.empty() && params.geomPlanarPrior) hostGeomCosts.assign(hostCosts.size(), 0.0f);
-    check(mpmvs_get(ctx, hostPlaneHypotheses.data(), hostCosts.data(), params.geomPlanarPrior && !hostGeomCosts.empty() ? hostGeomCosts.data() : nullptr), "mpmvs_get");
+    check(mpmvs_get(ctx, hostPlaneHypotheses.data(), hostCosts.data(), params.geomPlanarPrior ? hostGeomCosts.data() : nullptr), "mpmvs_get");
     host_state_valid = true;
 }
 
@@ -392,7 +401,11 @@ void ProcessProblem(std::vector<Scene>& Scenes, const int ID, bool geom_consiste
     MP.AllocatePatchMatch();
     MP.CudaMemInit(Scenes[ID]);
     tm.lap("Allocate + CudaMemInit");
+    // the first Run() of a planar-prior Problem whose prior is built on the device: no host code reads its maps (the
+    // reference's Run() would copy 46 MB that the second Run() overwrites), so its copies are deferred = never made
+    MP.SetDeferredFetch(planar_prior && !host_prior_requested());
     MP.Run();
+    MP.SetDeferredFetch(false);
     tm.lap("Run");
 
     const int width = MP.GetReferenceImageWidth();

@@ -10,8 +10,13 @@
 // sets with four or more cocircular points (common on a pixel grid) the Delaunay
 // triangulation is not unique and cv::Subdiv2D's choice, as well as its triangle
 // ORDER (which decides which triangle owns a shared border pixel), cannot be
-// reproduced without OpenCV: this file is "parity unpinned" against the
-// reference on those two points and pinned by its own property tests.
+// reproduced without OpenCV: "parity unpinned" against the reference on those
+// two points.  Everything else is pinned by fixtures generated without this
+// repository (tests/golden/make_prior_golden.py: vertex selection and raster as
+// step-by-step restatements, Delaunay triangle sets from Qhull on
+// general-position points, planes from numpy's SVD;
+// tests/test_prior_golden_cpu.py), the device kernels (csrc/pm_prior.hpp) equal
+// this file bit for bit (tests/test_prior_gpu.py).
 #include <algorithm>
 #include <cmath>
 #include <cstdint>

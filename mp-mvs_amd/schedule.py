@@ -31,7 +31,7 @@ def owned_problems(n_problems, rank, world):
 
 
 class SceneScheduler:
-    def __init__(self, cams, images, sources, make_handle, rank=0, world=1, dist=None, device_tensors=False, max_scale=2, workers=1):
+    def __init__(self, cams, images, sources, make_handle, rank=0, world=1, dist=None, device_tensors=False, max_scale=2, workers=1, iterations=None):
         """cams/images: all views of the scene; sources[i]: source-view ids of Problem i;
         make_handle(): a fresh PatchMatch handle (engine.create(local_rank) in production);
         workers: host threads per rank.  Within a pass the owned Problems are independent, so with
@@ -42,6 +42,7 @@ class SceneScheduler:
         self.n = len(sources)
         self.rank, self.world, self.dist = rank, world, dist
         self.max_scale = max_scale
+        self.iterations = iterations   # None: the reference's counts (3, geometric 2); tests shorten the schedule with it
         self.workers = max(1, int(workers))
         self.owned = owned_problems(self.n, rank, world)
         self.per_rank = (self.n + world - 1) // world
@@ -65,7 +66,7 @@ class SceneScheduler:
         dmin, dmax = kernel_depth_range(cam)
         p = PatchMatchParams(num_images=1 + len(self.sources[i]), depth_min=float(dmin), depth_max=float(dmax), max_scale=self.max_scale)
         p.geom_consistency = geom
-        p.max_iterations = 2 if geom else 3            # reference src/PatchMatch.cpp:655-665
+        p.max_iterations = self.iterations or (2 if geom else 3)   # reference src/PatchMatch.cpp:655-665
         p.geomPlanarPrior = bool(geom and planar)
         return p
 
@@ -95,7 +96,7 @@ class SceneScheduler:
                 h.set_prior(prior, mask)
             p.planar_prior = True
             p.geom_consistency = False
-            p.max_iterations = 3
+            p.max_iterations = self.iterations or 3
             h.run(p, (seed + PRIOR_SEED_OFFSET) & 0xFFFFFFFFFFFFFFFF)
         if self.device_tensors and not self.fetch_results:
             return None                                 # maps stay in HBM; fetch() brings them to the host on demand
@@ -103,31 +104,54 @@ class SceneScheduler:
         return planes, costs, g
 
     # -- exchange --------------------------------------------------------------
+    def _slot(self, j):
+        """position of Problem j's depth map in the gathered buffer: rank r's k-th slot holds Problem r + k * world"""
+        return (j % self.world) * self.per_rank + j // self.world
+
     def _attach_source_depths(self, i, h):
         srcs = self.sources[i]
         if self.device_tensors:
+            # the gathered buffer is read in place, slot by slot (no re-ordering copy); the call copies the maps into the
+            # context on the context's stream and returns when that copy is complete
             base = self.all_depths.data_ptr()
             stride = self.H * self.W * 4
-            h.set_src_depths_device([base + j * stride for j in srcs], [self.W] * len(srcs), [self.H] * len(srcs))
+            h.set_src_depths_device([base + self._slot(j) * stride for j in srcs], [self.W] * len(srcs), [self.H] * len(srcs))
         else:
-            h.set_src_depths([self.all_depths[j] for j in srcs])
+            h.set_src_depths([self.all_depths[self._slot(j)] for j in srcs])
+
+    def depth_maps(self):
+        """the depth maps of the last pass in Problem order, on the host: [n][H][W]"""
+        full = self.all_depths.cpu().numpy() if self.device_tensors else self.all_depths
+        return np.ascontiguousarray(full[[self._slot(j) for j in range(self.n)]])
 
     def _exchange(self):
-        """all-gather of the depth maps of this pass; doubles as the pass barrier"""
+        """all-gather of the depth maps of this pass; doubles as the pass barrier.
+
+        Stream ordering in device mode.  Three kinds of streams touch the buffers: torch's current stream (allocation, the
+        padding fill), the contexts' own non-blocking streams (export kernel; later the device-to-device copies of
+        set_src_depths_device) and RCCL's (ordered against torch's current stream by torch).  Non-blocking streams do not
+        order against torch's, so every hand-over is made explicit:
+          1. the padding fill on torch's stream is complete before the first export may write next to it;
+          2. each export is complete when its call returns (mpmvs_export_depth_device synchronises the context's stream),
+             so the collective, enqueued afterwards, sees every map;
+          3. the collective is complete (torch.cuda.synchronize) before this function returns, i.e. before any context of
+             the next pass copies its source maps out of the gathered buffer.
+        The gathered buffer is used as it arrives (rank-major slots, _slot()): no re-ordering kernel is left in flight."""
         if self.device_tensors:
             import torch
-            mine = torch.zeros((self.per_rank, self.H, self.W), dtype=torch.float32, device="cuda")
+            mine = torch.empty((self.per_rank, self.H, self.W), dtype=torch.float32, device="cuda")
+            if len(self.owned) < self.per_rank:
+                mine[len(self.owned):].zero_()            # padding slots of an uneven shard
+            torch.cuda.current_stream().synchronize()     # (1)
             for k, i in enumerate(self.owned):
-                self.handles[i].export_depth_device(mine[k].data_ptr())
+                self.handles[i].export_depth_device(mine[k].data_ptr())   # (2)
             if self.world > 1:
                 full = torch.empty((self.world * self.per_rank, self.H, self.W), dtype=torch.float32, device="cuda")
                 self.dist.all_gather_into_tensor(full, mine)
             else:
                 full = mine
-            torch.cuda.synchronize()
-            # rank r's k-th slot holds Problem r + k * world
-            order = [(i % self.world) * self.per_rank + i // self.world for i in range(self.n)]
-            self.all_depths = full[order].contiguous()
+            torch.cuda.synchronize()                      # (3)
+            self.all_depths = full
         else:
             mine = np.zeros((self.per_rank, self.H, self.W), np.float32)
             for k, i in enumerate(self.owned):
@@ -140,8 +164,7 @@ class SceneScheduler:
                 full = np.concatenate([o.numpy() for o in outs], 0)
             else:
                 full = mine
-            order = [(i % self.world) * self.per_rank + i // self.world for i in range(self.n)]
-            self.all_depths = np.ascontiguousarray(full[order])
+            self.all_depths = full
 
     # -- the pass schedule of reference src/main.cpp:20-41 ----------------------
     def run(self, geom_iterations=2, planar_prior=True, geom_planar_prior=True, seed=12345):

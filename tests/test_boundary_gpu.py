@@ -1,0 +1,187 @@
+"""The drop-in boundary as a maintainer would bind it: the stub of INTEGRATION.md section 2, call for call, on the RAW C ABI
+(ctypes function pointers of libmpmvs_hip.so -- no engine.HipPatchMatch, no C++ mirror), driven through the shipped pass
+schedule of reference src/main.cpp:20-41 (photometric -> geometric + planar-prior re-run -> geometric) and compared with the
+same schedule on the CPU oracle.
+
+What this pins that the other pipeline tests do not: PatchMatchCUDA::Run() ends with mpmvs_run_get(..., params.geomPlanarPrior
+? hostGeomCosts : NULL) exactly as reference src/PatchMatch.cu:1246-1251 does -- including the planar-prior re-run of a
+geometric pass, where geom_consistency is already cleared but geomPlanarPrior is still set (src/PatchMatch.cpp:535,655-665)."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class StubPatchMatchCUDA:
+    """INTEGRATION.md section 2, method for method.  Host arrays are numpy; every device-side action is one C-ABI call."""
+
+    def __init__(self, pm, fns, cams, imgs):
+        self.pm, self.f = pm, fns
+        self.cameras, self.images = cams, [np.ascontiguousarray(im, np.float32) for im in imgs]
+        self.params = pm.PatchMatchParams(num_images=len(cams), max_scale=1)
+        dmin, dmax = pm.synth.kernel_depth_range(cams[0])       # PatchMatchInit: depth_min * 0.6, depth_max * 1.2 (ref .cpp:929-930)
+        self.params.depth_min, self.params.depth_max = float(dmin), float(dmax)
+        self.ctx = None
+        self.hostGeomCosts = None
+        self.run_seed = 0
+        self.calls = []
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            msg = self.f["last_error"](self.ctx)
+            raise AssertionError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    # reference src/PatchMatch.cpp:655-670
+    def SetGeomConsistencyParams(self, geom_consistency, planar_prior):
+        self.params.geom_consistency = geom_consistency
+        if geom_consistency:
+            self.params.max_iterations = 2
+            self.params.geomPlanarPrior = planar_prior
+        else:
+            self.params.max_iterations = 3
+
+    def SetPlanarPriorParams(self):
+        self.params.planar_prior = True
+
+    # :960-976
+    def AllocatePatchMatch(self):
+        H, W = self.images[0].shape
+        self.ctx = self.f["create"](0)
+        assert self.ctx
+        self.hostPlaneHypotheses = np.zeros((H, W, 4), np.float32)
+        self.hostCosts = np.zeros((H, W), np.float32)
+        if self.params.geom_consistency:
+            self.hostGeomCosts = np.zeros((H, W), np.float32)
+
+    # :998-1089
+    def CudaMemInit(self, src_depths, prev):
+        n = len(self.cameras)
+        cam_arr = (self.pm.Camera * n)(*self.cameras)
+        ptrs = (C.POINTER(C.c_float) * n)(*[im.ctypes.data_as(C.POINTER(C.c_float)) for im in self.images])
+        pitches = (C.c_size_t * n)(*[im.strides[0] for im in self.images])
+        self._chk(self.f["set_views"](self.ctx, n, cam_arr, ptrs, pitches), "mpmvs_set_views")
+        if self.params.geom_consistency:
+            d = [np.ascontiguousarray(x, np.float32) for x in src_depths]
+            dp = (C.POINTER(C.c_float) * (n - 1))(*[x.ctypes.data_as(C.POINTER(C.c_float)) for x in d])
+            ws = (C.c_int * (n - 1))(*[x.shape[1] for x in d])
+            hs = (C.c_int * (n - 1))(*[x.shape[0] for x in d])
+            ps = (C.c_size_t * (n - 1))(*[x.strides[0] for x in d])
+            self._chk(self.f["set_src_depths"](self.ctx, n - 1, dp, ws, hs, ps), "mpmvs_set_src_depths")
+            self.hostPlaneHypotheses[...] = prev[0]      # "exactly as lines 1052-1084 do": the previous pass's maps
+            self.hostCosts[...] = prev[1]
+            self._chk(self.f["set_state"](self.ctx, self.hostPlaneHypotheses.ctypes.data, self.hostCosts.ctypes.data), "mpmvs_set_state")
+
+    # :978-996
+    def CudaPlanarPriorInitialization(self, prior, mask):
+        self.hostPriorPlanes = np.ascontiguousarray(prior, np.float32)
+        self.hostPlaneMask = np.ascontiguousarray(mask, np.uint32)
+        self._chk(self.f["set_prior"](self.ctx, self.hostPriorPlanes.ctypes.data, self.hostPlaneMask.ctypes.data), "mpmvs_set_prior")
+
+    # src/PatchMatch.cu:1188-1254
+    def Run(self):
+        geom = self.hostGeomCosts if self.params.geomPlanarPrior else None
+        self.calls.append((bool(self.params.geom_consistency), bool(self.params.planar_prior), bool(self.params.geomPlanarPrior), geom is not None))
+        self._chk(self.f["run_get"](self.ctx, C.byref(self.params), self.run_seed, self.hostPlaneHypotheses.ctypes.data, self.hostCosts.ctypes.data,
+                                    geom.ctypes.data if geom is not None else None), "mpmvs_run_get")
+
+    # :1091-1139
+    def Release(self):
+        self.f["destroy"](self.ctx)
+        self.ctx = None
+
+
+PRIOR_SEED_OFFSET = 0x9E3779B97F4A7C15
+
+
+def stub_process_problem(pm, fns, hostlib, cams, imgs, src_depths, prev, geom_consistency, planar_prior, seed, log):
+    """reference src/PatchMatch.cpp:506-638 over the stub: one PatchMatchCUDA object (= one context) per call"""
+    MP = StubPatchMatchCUDA(pm, fns, cams, imgs)
+    MP.SetGeomConsistencyParams(geom_consistency, planar_prior)
+    MP.AllocatePatchMatch()
+    MP.CudaMemInit(src_depths, prev)
+    MP.run_seed = seed
+    MP.Run()
+    if planar_prior:
+        geom_after_first = None if MP.hostGeomCosts is None else MP.hostGeomCosts.copy()
+        MP.SetPlanarPriorParams()
+        MP.SetGeomConsistencyParams(False, True)
+        gpp = bool(MP.params.geomPlanarPrior)
+        # GetTriangulateVertices, DelaunayTriangulation, raster, GetPriorPlaneParams, range test: the reference's host code (:532-604)
+        prior, mask, ntri = hostlib.build_prior(cams[0], MP.hostPlaneHypotheses, MP.hostCosts, MP.hostGeomCosts if gpp else None, gpp,
+                                                MP.params.depth_min, MP.params.depth_max)
+        assert ntri > 0
+        MP.CudaPlanarPriorInitialization(prior, mask)
+        MP.run_seed = (seed + PRIOR_SEED_OFFSET) & 0xFFFFFFFFFFFFFFFF
+        MP.Run()
+        if gpp:
+            # ref .cu:1248 in the prior re-run: cudaGeomCosts is copied again and still holds the geometric Run()'s map
+            assert np.array_equal(MP.hostGeomCosts, geom_after_first)
+        MP.SetGeomConsistencyParams(geom_consistency, planar_prior)
+    out = (MP.hostPlaneHypotheses.copy(), MP.hostCosts.copy())
+    log.extend(MP.calls)
+    MP.Release()
+    return out
+
+
+def test_integration_stub_on_the_shipped_schedule(pm, oracle, engine):
+    from test_pipeline_gpu import oracle_pipeline
+    hostlib = importlib.import_module("mp-mvs_amd.hostlib")
+    _, fns = engine.load()
+    W, H = 128, 96
+    sc = pm.synth.make_problem_scene(W, H, n_src=4, spacing=0.4, quantize=True)
+    cams, imgs = sc.problem(0, [1, 2, 3, 4])
+    rng = np.random.default_rng(3)
+    src_depths = [sc.views[i].gt_depth * (1.0 + 0.005 * rng.standard_normal((H, W))).astype(np.float32) for i in (1, 2, 3, 4)]
+    SEED, GEOM_IT = 4242, 2
+    log = []
+    # src/main.cpp:20-41 with the shipped config.yaml (planar_prior, geom_consistency, geomPlanarPrior all on)
+    prev = stub_process_problem(pm, fns, hostlib, cams, imgs, None, None, False, False, SEED, log)
+    for g in range(GEOM_IT):
+        pp = g != GEOM_IT - 1
+        prev = stub_process_problem(pm, fns, hostlib, cams, imgs, src_depths, prev, True, pp, SEED + 1 + g, log)
+    # the sequence of Run() calls: (geom_consistency, planar_prior, geomPlanarPrior, hostGeomCosts passed)
+    assert log == [(False, False, False, False), (True, False, True, True), (False, True, True, True), (True, False, False, False)]
+    planes, costs = oracle_pipeline(pm, oracle, hostlib, cams, imgs, src_depths, 1, GEOM_IT, True, True, SEED)
+    assert np.array_equal(prev[0], planes) and np.array_equal(prev[1], costs)
+    gt = sc.views[0].gt_depth
+    assert (np.abs(prev[0][..., 3] - gt) / gt < 0.05).mean() > 0.85
+
+
+def test_run_get_geom_buffer_follows_the_reference_rule(pm, oracle, engine):
+    """any Run() accepts a geometric-cost buffer and returns what cudaGeomCosts holds (ref .cu:1248 copies by geomPlanarPrior,
+    not by the mode of the Run()): zeros on a fresh context, the geometric Run()'s map afterwards"""
+    sc = pm.synth.make_problem_scene(96, 64, n_src=3, spacing=0.5, quantize=True)
+    cams, imgs = sc.problem(0, [1, 2, 3])
+    gpu = engine.create(0)
+    gpu.set_views(cams, imgs)
+    dmin, dmax = pm.synth.kernel_depth_range(cams[0])
+    prm = pm.PatchMatchParams(num_images=4, depth_min=float(dmin), depth_max=float(dmax), max_scale=0)
+    p, c, g = np.empty((64, 96, 4), np.float32), np.empty((64, 96), np.float32), np.full((64, 96), -1.0, np.float32)
+    prm.geomPlanarPrior = True          # stale flag on a photometric Run(): legal in the reference
+    gpu.run_into(prm, 7, p, c, g)
+    assert not g.any()
+    rng = np.random.default_rng(3)
+    depths = [sc.views[i].gt_depth * (1.0 + 0.01 * rng.standard_normal((64, 96))).astype(np.float32) for i in (1, 2, 3)]
+    gpu.set_src_depths(depths)
+    prm.geom_consistency, prm.max_iterations = True, 2
+    g1 = np.empty((64, 96), np.float32)
+    gpu.run_into(prm, 8, p, c, g1)
+    assert g1.any()
+    # the same two Run()s on the oracle (the state persists on the context between them)
+    cpu = oracle.create()
+    cpu.set_views(cams, imgs)
+    prm_o = pm.PatchMatchParams(num_images=4, depth_min=float(dmin), depth_max=float(dmax), max_scale=0)
+    cpu.run(prm_o, 7)
+    cpu.set_src_depths(depths)
+    prm_o.geom_consistency, prm_o.max_iterations = True, 2
+    cpu.run(prm_o, 8)
+    po, co, go = cpu.get(geom=True)
+    assert np.array_equal(p, po) and np.array_equal(c, co) and np.array_equal(g1, go)
+    # a planar-prior style re-run without geometric consistency leaves the map alone and hands it out again
+    prm.geom_consistency, prm.max_iterations = False, 3
+    g2 = np.empty((64, 96), np.float32)
+    gpu.run_into(prm, 9, p, c, g2)
+    assert np.array_equal(g2, g1)

@@ -100,7 +100,7 @@ def test_scheduler_device_exchange_bit_exact(pm, oracle, engine):
     gpu = sched.SceneScheduler(cams, imgs, neigh, lambda: engine.create(0), device_tensors=True, max_scale=1)
     cpu = sched.SceneScheduler(cams, imgs, neigh, oracle.create, device_tensors=False, max_scale=1)
     rg, rc = gpu.run(**kw), cpu.run(**kw)
-    assert np.array_equal(gpu.all_depths.cpu().numpy(), cpu.all_depths)
+    assert np.array_equal(gpu.depth_maps(), cpu.depth_maps())
     for i in range(6):
         assert np.array_equal(rg[i][0], rc[i][0]) and np.array_equal(rg[i][1], rc[i][1]), f"problem {i}"
     # worker threads overlap host and device work of different Problems; same bits
@@ -108,6 +108,38 @@ def test_scheduler_device_exchange_bit_exact(pm, oracle, engine):
     r3 = gpu3.run(**kw)
     for i in range(6):
         assert np.array_equal(r3[i][0], rc[i][0]) and np.array_equal(r3[i][1], rc[i][1]), f"problem {i} (3 workers)"
+
+
+def test_scheduler_device_exchange_full_size_bit_exact(pm, engine):
+    """The device-resident exchange at BASELINE size: 16 Problems of 1600x1200 (4x4 camera grid, 8 source views each), one
+    photometric and one geometric pass of one iteration, worker threads on.  Depth maps exchanged in HBM (export -> gathered
+    buffer -> device-to-device copies on the contexts' own streams; state resident) against the same schedule with every map
+    staged through host arrays (get -> numpy -> set_src_depths / set_state), which no stream-ordering mistake can touch.
+    At this size a map is 7.7 MB and the gathered buffer 123 MB: a copy or fill that is still in flight when the next stage
+    reads or overwrites the buffer changes bits (tests at 64x48 cannot see that)."""
+    from concurrent.futures import ThreadPoolExecutor
+    sched = importlib.import_module("mp-mvs_amd.schedule")
+    W, H, G = 1600, 1200, 4
+    centers = [((i - (G - 1) / 2.0) * 0.15, (j - (G - 1) / 2.0) * 0.15, 0.0) for j in range(G) for i in range(G)]
+    with ThreadPoolExecutor(8) as pool:       # numpy releases the GIL in the big array operations of the renderer
+        views = list(pool.map(lambda i: pm.synth.make_scene(W, H, centers, quantize=True, only={i}).views[i], range(G * G)))
+    cams, imgs = [v.cam for v in views], [v.image for v in views]
+    neigh = []
+    for j in range(G):
+        for i in range(G):
+            cand = sorted(((ii - i) ** 2 + (jj - j) ** 2, jj * G + ii) for jj in range(G) for ii in range(G) if (ii, jj) != (i, j))
+            neigh.append([c[1] for c in cand[:8]])
+    kw = dict(geom_iterations=1, planar_prior=False, geom_planar_prior=False, seed=4711)
+    dev = sched.SceneScheduler(cams, imgs, neigh, lambda: engine.create(0), device_tensors=True, max_scale=0, workers=4, iterations=1)
+    rd = dev.run(**kw)
+    dd = dev.depth_maps()
+    del dev
+    host = sched.SceneScheduler(cams, imgs, neigh, lambda: engine.create(0), device_tensors=False, max_scale=0, workers=1, iterations=1)
+    rh = host.run(**kw)
+    assert np.array_equal(dd, host.depth_maps())
+    for i in range(G * G):
+        assert np.array_equal(rd[i][0], rh[i][0]) and np.array_equal(rd[i][1], rh[i][1]) and np.array_equal(rd[i][2], rh[i][2]), f"problem {i}"
+    assert np.isfinite(dd).all() and dd.min() > 0
 
 
 def test_folder_pipeline_matches_oracle(pm, oracle, engine, tmp_path):

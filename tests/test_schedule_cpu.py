@@ -27,7 +27,7 @@ def _run(rank, world, dist, kw):
     cams, imgs, neigh = _scene()
     s = sched.SceneScheduler(cams, imgs, neigh, ob.create, rank=rank, world=world, dist=dist, max_scale=0, workers=2 if world > 1 else 1)
     res = s.run(**kw)
-    return {i: (r[0], r[1]) for i, r in res.items()}, s.all_depths
+    return {i: (r[0], r[1]) for i, r in res.items()}, s.depth_maps()
 
 
 def _worker(rank, world, port, kw, outdir):
