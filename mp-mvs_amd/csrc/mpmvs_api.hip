@@ -649,7 +649,7 @@ static dim3 checker_grid(const mpmvs_ctx* c, const LaunchArgs& a) {
 template <bool GEOM, bool PRIOR, bool U8, int SCALE>
 static void launch_update3(mpmvs_ctx* c, const LaunchArgs& a) {
     const dim3 grid = checker_grid<U8>(c, a);
-    const size_t lds = ncc_lds_bytes(kChkBlockW<U8>, kChkBlockH<U8>, SCALE);
+    const size_t lds = update_lds_bytes();
     const int V = c->hP.V;
     if (V <= 8)
         hipLaunchKernelGGL((k_update<GEOM, PRIOR, 8, U8, SCALE>), grid, dim3(256), lds, c->stream, c->dP, c->S, a);

@@ -125,6 +125,13 @@ inline size_t ncc_lds_bytes(int bw, int bh, int scale) {
     return (size_t)(kLdsWeightFloats + (tile <= 2048 ? tile : 0)) * sizeof(float);
 }
 
+// The update kernel re-uses the tile region after its prologue as the exchange area of the compacted refinement (below):
+// 2 KB per wave, whether or not the tile itself is staged in LDS.  72 KB + 8 KB = half a CU's LDS: two blocks per CU as before.
+constexpr int kXchgBytesPerWave = 2048;
+constexpr int kLdsXchgFloats = 4 * kXchgBytesPerWave / 4;
+inline size_t update_lds_bytes() { return (size_t)(kLdsWeightFloats + kLdsXchgFloats) * sizeof(float); }
+static_assert(kLdsXchgFloats == 2048, "the exchange area takes the place of the largest LDS-resident reference tile (Win::tile_in_lds)");
+
 // ---------------------------------------------------------------------------
 // InitializeScore, ref .cu:536-573 (+ :497-534)
 // ---------------------------------------------------------------------------
@@ -245,6 +252,8 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
     const bool valid = checker_pixel<U8>(P, a, x, y, x0, y0);
     RefWin rw;
     ref_window_of_pixel<SCALE, kChkBlockW<U8>, kChkBlockH<U8>>(P, x, y, x0, y0, valid, a.spatial, a.two_sc, rw);
+    // the tile region becomes the exchange area of the refinement: every wave must be done reading the tile first
+    if constexpr (Win<SCALE, kChkBlockW<U8>, kChkBlockH<U8>>::tile_in_lds) __syncthreads();
     if (!valid) return;
     const int W = P.W, Hh = P.H, V = P.V;
     const int idx = y * W + x;
@@ -545,67 +554,135 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
     park_n[6] = n_pert.x, park_n[7] = n_pert.y, park_n[8] = n_pert.z;
     park_d[0] = depth_now, park_d[1] = depth_rand, park_d[2] = depth_pert;
     }
-    // candidates: (d_rand,n) (d,n_rand) (d_rand,n_rand) (d,n_pert) (d_pert,n)   ref .cu:674-675.  Their evaluations do not depend
-    // on each other (only the acceptance below is sequential), so they too run view by view.
-    float ref_m[5 * 3], ref_gp[5 * 3], tcs[5], tgs[5];
-    keep_in_memory(ref_m);
-    if (GEOM) keep_in_memory(ref_gp);
+    // candidates: (d_rand,n) (d,n_rand) (d_rand,n_rand) (d,n_pert) (d_pert,n)   ref .cu:674-675.
+    //
+    // Their evaluations do not depend on each other (only the acceptance below is sequential) and MOST OF THEM CANNOT WIN:
+    //   * a candidate whose depth lies outside [depth_min, depth_max] is never accepted (ref .cu:700,713);
+    //   * outside the masked-prior branch a candidate is accepted only if sum_v w_v (c_v [+ g_v]) / weight_norm < cost_now
+    //     (ref .cu:696,713).  Every term is >= 0, fp32 addition of non-negative terms and the division by the positive norm
+    //     are monotone, and cost_now only decreases from one candidate to the next: once a candidate's running sum has reached
+    //     T >= cost_now * weight_norm (exact product, rounded UP) with the cost_now the refinement started with, its quotient
+    //     is >= that cost_now whatever the remaining views add -- they are dead work the reference performs (:681) and nothing
+    //     reads.  (Measured with the oracle's statistics hook, tools/prune_stats.py: 45 % of a lane's refinement evaluations.)
+    // A lane cannot profit from its own dead evaluations while other lanes of the wave are still live, so the live (pixel,
+    // candidate) pairs of a view are DEALT TO THE LANES OF THE WAVE through LDS: every lane publishes the planes of its live
+    // candidates at consecutive slots (ballot + mbcnt), lane j evaluates item j of the round for whoever owns it -- with the
+    // owner's pixel, weight records and window statistics -- and the owner collects the costs in ascending view order, exactly
+    // the sums of the uncompacted loop.  38 -> 25 evaluation rounds per wave and update on the cfg-1 scene.
+    float cpl[5 * 4], tcs[5], tgs[5];
+    keep_in_memory(cpl);
+    uint32_t dead = 0;
+#pragma unroll
     for (int ci = 0; ci < 5; ++ci) {
         const int ni = 3 * ((ci == 1 || ci == 2) ? 1 : (ci == 3 ? 2 : 0));
         float4 pl;
         pl.x = park_n[ni], pl.y = park_n[ni + 1], pl.z = park_n[ni + 2];
         pl.w = plane_offset(P, x, y, park_d[(ci == 0 || ci == 2) ? 1 : (ci == 4 ? 2 : 0)], pl);
-        float m0, m1, m2;
-        plane_to_m(P, pl, m0, m1, m2);
-        ref_m[3 * ci] = m0, ref_m[3 * ci + 1] = m1, ref_m[3 * ci + 2] = m2;
-        if (GEOM) {
-            const GeomPoint gp = geom_world_point(P, pl, x, y);
-            ref_gp[3 * ci] = gp.w0, ref_gp[3 * ci + 1] = gp.w1, ref_gp[3 * ci + 2] = gp.w2;
-        }
+        cpl[4 * ci] = pl.x, cpl[4 * ci + 1] = pl.y, cpl[4 * ci + 2] = pl.z, cpl[4 * ci + 3] = pl.w;
+        const float db = depth_from_plane(P, pl, x, y);
+        if (!(db >= a.depth_min && db <= a.depth_max)) dead |= 1u << ci;
         tcs[ci] = 0.0f;
         tgs[ci] = 0.0f;
     }
+    // T: the exact product cost_now * weight_norm rounded up (the fp32 product is within half an ulp of it; one ulp more is
+    // above it; both factors are finite and >= 0).  Masked prior pixels accept on another criterion (ref .cu:707): no threshold.
+    const float T = masked ? __uint_as_float(0x7f800000u) : __uint_as_float(__float_as_uint(cost_now * weight_norm) + 1u);
     {
+        constexpr int kLanesPerRow = 64 / kWaveRows<U8>;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        char* const xw = reinterpret_cast<char*>(pm_lds + kLdsWeightFloats) + wv * kXchgBytesPerWave;
+        float4* const x_rec = reinterpret_cast<float4*>(xw);                           // [64] plane of the item
+        float2* const x_res = reinterpret_cast<float2*>(xw + 1024);                    // [64] (photometric cost, geometric term)
+        unsigned short* const x_id = reinterpret_cast<unsigned short*>(xw + 1536);     // [64] owner lane
+        const int wave_y = y0 + (wv / PM_BLOCK_WAVES_X) * kWaveRows<U8>;
+        const int wave_x = x0 + 2 * (wv % PM_BLOCK_WAVES_X) * kLanesPerRow;
+        // lanes without a pixel (image border) have left the kernel: the items of a round go to the lanes that are still here,
+        // the r-th of them taking slot r
+        const unsigned long long here = __ballot(1);
+        const int n_here = __builtin_popcountll(here);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u));
         float w_next = view_w[0];
         for (int v = 0; v < V; ++v) {
             const float w = w_next;
             w_next = view_w[v + 1 < MAXV ? v + 1 : v];
-            if (!(w > 0.0f)) continue;
-            float n0 = ref_m[0], n1 = ref_m[1], n2 = ref_m[2];
+            const uint32_t live = (w > 0.0f) ? (~dead & 31u) : 0u;
+            int pos[5], total = 0;
+#pragma unroll
             for (int ci = 0; ci < 5; ++ci) {
-                const float m0 = n0, m1 = n1, m2 = n2;
-                const int nxt = 3 * (ci < 4 ? ci + 1 : ci);
-                n0 = ref_m[nxt], n1 = ref_m[nxt + 1], n2 = ref_m[nxt + 2];
-                const float c = ncc_cost<U8, SCALE>(P.views[v], rw, x, y, m0, m1, m2);
-                if (GEOM) {
-                    const GeomPoint gp{ref_gp[3 * ci], ref_gp[3 * ci + 1], ref_gp[3 * ci + 2]};
-                    const float gt = 0.2f * geom_cost_view<kGeomCall>(P, P.views[v], gp, x, y);
-                    tcs[ci] += w * (c + gt);
-                    tgs[ci] += view_w[ci] * gt;  // the candidate index used as view index, ref .cu:689
-                } else {
-                    tcs[ci] += w * c;
+                const unsigned long long b = __ballot((live >> ci) & 1u);
+                pos[ci] = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                total += __builtin_popcountll(b);
+            }
+            for (int base = 0; base < total; base += n_here) {
+                // owners publish the items of this round
+#pragma unroll
+                for (int ci = 0; ci < 5; ++ci)
+                    if (((live >> ci) & 1u) && (unsigned)(pos[ci] - base) < (unsigned)n_here) {
+                        const int slot = pos[ci] - base;
+                        x_rec[slot] = make_float4(cpl[4 * ci], cpl[4 * ci + 1], cpl[4 * ci + 2], cpl[4 * ci + 3]);
+                        x_id[slot] = (unsigned short)lane;
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // the lane of rank r evaluates item base + r with its owner's pixel, weight records and window statistics
+                const bool have = base + rank < total;
+                const int owner = have ? (int)x_id[rank] : lane;
+                const float4 ipl = x_rec[rank];
+                RefWin orw;
+                orw.lw = reinterpret_cast<const float4*>(pm_lds) + ((threadIdx.x & ~63u) + owner);
+                orw.inv_w = __int_as_float(__builtin_amdgcn_ds_bpermute(owner << 2, __float_as_int(rw.inv_w)));
+                orw.mean_r = __int_as_float(__builtin_amdgcn_ds_bpermute(owner << 2, __float_as_int(rw.mean_r)));
+                orw.var_r = __int_as_float(__builtin_amdgcn_ds_bpermute(owner << 2, __float_as_int(rw.var_r)));
+                if (have) {
+                    const int oy = wave_y + owner / kLanesPerRow;
+                    const int ox = wave_x + 2 * (owner % kLanesPerRow) + ((oy + a.parity) & 1);
+                    float m0, m1, m2;
+                    plane_to_m(P, ipl, m0, m1, m2);
+                    const float c = ncc_cost<U8, SCALE>(P.views[v], orw, ox, oy, m0, m1, m2);
+                    float gt = 0.0f;
+                    if (GEOM) gt = 0.2f * geom_cost_view<kGeomCall>(P, P.views[v], geom_world_point(P, ipl, ox, oy), ox, oy);
+                    x_res[rank] = make_float2(c, gt);
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // owners collect: for a fixed candidate the views are still added in ascending order
+#pragma unroll
+                for (int ci = 0; ci < 5; ++ci)
+                    if (((live >> ci) & 1u) && (unsigned)(pos[ci] - base) < (unsigned)n_here) {
+                        const float2 r = x_res[pos[ci] - base];
+                        if (GEOM) {
+                            tcs[ci] += w * (r.x + r.y);
+                            tgs[ci] += view_w[ci] * r.y;  // the candidate index used as view index, ref .cu:689
+                        } else {
+                            tcs[ci] += w * r.x;
+                        }
+                        if (tcs[ci] >= T) dead |= 1u << ci;
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
     }
+#pragma unroll
     for (int ci = 0; ci < 5; ++ci) {
-        const int ni = 3 * ((ci == 1 || ci == 2) ? 1 : (ci == 3 ? 2 : 0));
+        if ((dead >> ci) & 1u) continue;  // out of range, or provably not below cost_now: the reference's tests below are false
         float4 pl;
-        pl.x = park_n[ni], pl.y = park_n[ni + 1], pl.z = park_n[ni + 2];
-        cand_depth = park_d[(ci == 0 || ci == 2) ? 1 : (ci == 4 ? 2 : 0)];
-        pl.w = plane_offset(P, x, y, cand_depth, pl);
+        pl.x = cpl[4 * ci], pl.y = cpl[4 * ci + 1], pl.z = cpl[4 * ci + 2], pl.w = cpl[4 * ci + 3];
         const float tc = tcs[ci] / weight_norm;
         const float tg = GEOM ? tgs[ci] / weight_norm : 0.0f;
-        const float db = depth_from_plane(P, pl, x, y);
         if (masked) {
+            cand_depth = park_d[(ci == 0 || ci == 2) ? 1 : (ci == 4 ? 2 : 0)];
             const float ac = (pp.x * pl.x + pp.y * pl.y) + pp.z * pl.z;
             const float pr = prior_term<kPriorCall>(cand_depth - depth_prior, ac, two_ds2, two_as2);
             const float rtc = d_exp(-tc * tc / beta) * pr;
-            if (db >= a.depth_min && db <= a.depth_max && rtc > restricted_cost) {
+            if (rtc > restricted_cost) {
                 plane_now = pl;
                 cost_now = tc;
             }
-        } else if (db >= a.depth_min && db <= a.depth_max && tc < cost_now) {
+        } else if (tc < cost_now) {
             plane_now = pl;
             cost_now = tc;
             geom_now = tg;

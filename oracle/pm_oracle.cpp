@@ -674,6 +674,14 @@ inline float prior_term(float depth_diff, float angle_cos, float two_ds2, float 
     return 0.5f + det_exp(-depth_diff * depth_diff / two_ds2) * det_exp(-ad * ad / two_as2);
 }
 
+// Statistics hook for sizing kernel optimisations (tools/prune_stats.py): when set, every update_pixel records, per
+// refinement candidate, after how many views (ascending view index) its running weighted sum has provably lost against the
+// cost the refinement started from -- i.e. which evaluations of the refinement nothing reads.  The oracle itself always
+// evaluates everything (ref .cu:681).  g_stat_death[idx * 5 + i]: -1 = depth out of range (dead from the start), v = the
+// candidate is decided after the evaluation of view v, V = never; g_stat_wmask[idx]: views with weight > 0.
+static int8_t* g_stat_death = nullptr;
+static uint32_t* g_stat_wmask = nullptr;
+
 void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int iter, int scale, int px, int py) {
     const int W = c.W, Hh = c.H;
     const int idx = py * W + px;
@@ -921,6 +929,13 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
         const float depth_pert = rng_uniform(g) * (dmax_p - dmin_p) + dmin_p;  // loop never repeats (quirk a-10 ii)
         const F4 n_pert = perturbed_normal(cam, px, py, plane_now, g, 0.06283185f /* 0.02*pi */);
 
+        const float cost_now_at_refinement_start = cost_now;
+        if (g_stat_wmask) {
+            uint32_t m = 0;
+            for (int v = 0; v < V; ++v)
+                if (view_w[v] > 0.0f) m |= 1u << v;
+            g_stat_wmask[idx] = m;
+        }
         const float depths5[5] = {depth_rand, depth_now, depth_rand, depth_now, depth_pert};
         const F4 normals5[5] = {plane_now, n_rand, n_rand, n_pert, plane_now};
         for (int i = 0; i < 5; ++i) {
@@ -931,6 +946,8 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
             float cv[kMaxViews];
             for (int v = 0; v < V; ++v) cv[v] = ncc_cost(c, rw, px, py, m, v);
             float tc = 0.0f, tg = 0.0f;
+            int stat_death = V;
+            const float stat_cost_start = cost_now_at_refinement_start;
             for (int v = 0; v < V; ++v) {
                 if (view_w[v] > 0.0f) {
                     if (geom) {
@@ -940,7 +957,12 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
                     } else {
                         tc += view_w[v] * cv[v];
                     }
+                    if (stat_death == V && !masked && tc / weight_norm >= stat_cost_start) stat_death = v;
                 }
+            }
+            if (g_stat_death) {
+                const float dbs = depth_from_plane(cam, tp, px, py);
+                g_stat_death[(size_t)idx * 5 + i] = (int8_t)((dbs >= prm.depth_min && dbs <= prm.depth_max) ? stat_death : -1);
             }
             tc /= weight_norm;
             if (geom) tg /= weight_norm;
@@ -1371,6 +1393,11 @@ int orc_homography(orc_ctx* h, const float* plane4, int v, float* H9) {
     for (int r = 0; r < 3; ++r)
         for (int k = 0; k < 3; ++k) H9[r * 3 + k] = fmaf(-c.vc[v].b[r], m[k], c.vc[v].A[r * 3 + k]);
     return 0;
+}
+// statistics hook (see g_stat_death): buffers of H*W*5 int8 and H*W uint32, or NULL to switch it off
+void orc_set_refinement_stats(int8_t* death5, uint32_t* wmask) {
+    g_stat_death = death5;
+    g_stat_wmask = wmask;
 }
 int orc_num_threads(void) {
 #if defined(_OPENMP)
