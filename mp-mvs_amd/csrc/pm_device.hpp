@@ -569,7 +569,7 @@ PM_DEV void plane_to_m(const ProblemDev& P, const float4 pl, float& m0, float& m
 // ref .cu:325-414 ComputeBilateralNCC for one (hypothesis, source view), given the homography H = A - b m^T of the
 // pair, the texture handle of the view (wave-uniform SrcTex / SrcTex8) and the LDS weight records of the pixel
 // (rw.lw[rec * LWSTRIDE]).
-template <bool U8, int LWSTRIDE, int SCALE, class TEX>
+template <bool U8, int LWSTRIDE, int SCALE, bool DEEP, class TEX>
 PM_DEV float ncc_core(const TEX& tex, float wf, float hf, float H0, float H1, float H2, float H3, float H4, float H5, float H6, float H7, float H8,
                       const RefWin& rw, int px, int py) {
     constexpr int step = 2 << SCALE, radius = 5 * step / 2;
@@ -641,8 +641,9 @@ PM_DEV float ncc_core(const TEX& tex, float wf, float hf, float H0, float H1, fl
 #pragma unroll
         for (int j = 0; j < 3; ++j) wq[j] = rw.lw[(a * 3 + j) * LWSTRIDE];
     };
-    // fp16 texels: TWO columns ahead (12 .. 18 gathers in flight, 3.26 -> 3.22 ms); the fp32 texels have no registers for that
-    if constexpr (U8) {
+    // DEEP: the gathers of TWO columns ahead are in flight (12 .. 18 loads; fp16 texels 3.26 -> 3.22 ms per update launch).  A
+    // column of fp32 texels takes 24 registers, so the callers ask for it only where the kernel around it has them to spare.
+    if constexpr (DEEP) {
         BilinearTap<U8> tapA[6], tapB[6], tapC[6];
         float4 wA[3], wB[3];
         load_weights(0, wA);
@@ -694,7 +695,7 @@ PM_DEV float ncc_core(const TEX& tex, float wf, float hf, float H0, float H1, fl
 }
 
 // one-thread-per-pixel kernels: wave-uniform source view (constants through the scalar cache)
-template <bool U8, int SCALE>
+template <bool U8, int SCALE, bool DEEP = U8>
 PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, float m0, float m1, float m2) {
     const float H0 = __builtin_fmaf(-vw.b[0], m0, vw.A[0]);
     const float H1 = __builtin_fmaf(-vw.b[0], m1, vw.A[1]);
@@ -711,7 +712,7 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, float
         else
             return make_src_tex(vw);
     }();
-    return ncc_core<U8, kBlockThreads, SCALE>(tex, vw.wf, vw.hf, H0, H1, H2, H3, H4, H5, H6, H7, H8, rw, px, py);
+    return ncc_core<U8, kBlockThreads, SCALE, DEEP>(tex, vw.wf, vw.hf, H0, H1, H2, H3, H4, H5, H6, H7, H8, rw, px, py);
 }
 
 // ---------------------------------------------------------------------------

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_init(const ProblemDe
     plane_to_m(P, pl, m0, m1, m2);
     int n_valid = 0;
     for (int v = 0; v < V; ++v) {
-        const float c = ncc_cost<U8, SCALE>(P.views[v], rw, x, y, m0, m1, m2);
+        const float c = ncc_cost<U8, SCALE, true>(P.views[v], rw, x, y, m0, m1, m2);
         cv[v] = c;
         sorted[v] = c;
         if (c < 2.0f) n_valid++;
@@ -242,6 +242,12 @@ template <bool GEOM, bool PRIOR, int MAXV, bool U8, int SCALE>
 __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
     const ProblemDev& P = *Pp;
     constexpr bool kGeomCall = MAXV > 8;  // see geom_cost_view
+    // gathers of two window columns ahead (ncc_core): always with the 8-byte texels; with the 16-byte ones where the variant
+    // still has the 24 registers of a third column (8 views; more views spill 4 .. 81 registers around the evaluations)
+#ifndef PM_F32_DEEP_WHEN
+#define PM_F32_DEEP_WHEN (MAXV == 8)
+#endif
+    constexpr bool kDeep = U8 || PM_F32_DEEP_WHEN;
     constexpr bool kPriorCall = MAXV > 8 || kWavesPerSimd<U8> >= 3;
 #ifdef PM_PARK_ALL
     constexpr bool kPark = true;
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
             n0 = cand_m[nxt], n1 = cand_m[nxt + 1], n2 = cand_m[nxt + 2];
             float c;
             if ((flags >> slot) & 1u)
-                c = ncc_cost<U8, SCALE>(P.views[v], rw, x, y, m0, m1, m2);
+                c = ncc_cost<U8, SCALE, kDeep>(P.views[v], rw, x, y, m0, m1, m2);
             else
                 c = (slot == 0 && v == 0) ? 2.0f : 0.0f;  // `= {2.0f}` initialiser quirk, ref .cu:795
             cost_arr[slot * MAXV + v] = c;
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
             const float w = w_next;
             w_next = view_w[v + 1 < MAXV ? v + 1 : v];
             if (!(w > 0.0f)) continue;
-            const float c = ncc_cost<U8, SCALE>(P.views[v], rw, x, y, m0, m1, m2);
+            const float c = ncc_cost<U8, SCALE, kDeep>(P.views[v], rw, x, y, m0, m1, m2);
             if (GEOM) {
                 const float gt = 0.2f * geom_cost_view<kGeomCall>(P, P.views[v], gp, x, y);
                 tc += w * (c + gt);
@@ -639,7 +645,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
                     const int ox = wave_x + 2 * (owner % kLanesPerRow) + ((oy + a.parity) & 1);
                     float m0, m1, m2;
                     plane_to_m(P, ipl, m0, m1, m2);
-                    const float c = ncc_cost<U8, SCALE>(P.views[v], orw, ox, oy, m0, m1, m2);
+                    const float c = ncc_cost<U8, SCALE, kDeep>(P.views[v], orw, ox, oy, m0, m1, m2);
                     float gt = 0.0f;
                     if (GEOM) gt = 0.2f * geom_cost_view<kGeomCall>(P, P.views[v], geom_world_point(P, ipl, ox, oy), ox, oy);
                     x_res[rank] = make_float2(c, gt);
@@ -874,7 +880,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_eval_ncc(const Probl
     for (int h = 0; h < nh; ++h) {
         float m0, m1, m2;
         plane_to_m(P, planes[h * wh + idx], m0, m1, m2);
-        for (int v = 0; v < P.V; ++v) out[((long)h * P.V + v) * wh + idx] = ncc_cost<U8, SCALE>(P.views[v], rw, x, y, m0, m1, m2);
+        for (int v = 0; v < P.V; ++v) out[((long)h * P.V + v) * wh + idx] = ncc_cost<U8, SCALE, true>(P.views[v], rw, x, y, m0, m1, m2);
     }
 }
 

@@ -681,6 +681,10 @@ inline float prior_term(float depth_diff, float angle_cos, float two_ds2, float 
 // candidate is decided after the evaluation of view v, V = never; g_stat_wmask[idx]: views with weight > 0.
 static int8_t* g_stat_death = nullptr;
 static uint32_t* g_stat_wmask = nullptr;
+// phase A: g_stat_bad3[idx * 32 + v] = the candidate slot (0..7) at which view v's count of costs > 1.2 reaches 3 -- from then
+// on the view's sampling probability is 0 whatever the remaining candidates cost (ref .cu:847-853) -- or 8; [idx * 32 + 31] =
+// the bitmask of flagged (existing) candidates
+static uint8_t* g_stat_bad3 = nullptr;
 
 void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int iter, int scale, int px, int py) {
     const int W = c.W, Hh = c.H;
@@ -725,6 +729,17 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
         }
     }
 
+    if (g_stat_bad3) {
+        for (int v = 0; v < V; ++v) {
+            int nb = 0, at = 8;
+            for (int j = 0; j < 8; ++j)
+                if (cost_arr[j][v] > 1.2f && ++nb == 3 && at == 8) at = j;
+            g_stat_bad3[(size_t)idx * 32 + v] = (uint8_t)at;
+        }
+        uint8_t fm = 0;
+        for (int j = 0; j < 8; ++j) fm |= flag[j] ? (1u << j) : 0;
+        g_stat_bad3[(size_t)idx * 32 + 31] = fm;
+    }
     // -- view weights (ref .cu:821-867)
     float view_w[kMaxViews];
     {
@@ -1399,6 +1414,8 @@ void orc_set_refinement_stats(int8_t* death5, uint32_t* wmask) {
     g_stat_death = death5;
     g_stat_wmask = wmask;
 }
+// phase-A statistics (see g_stat_bad3): a buffer of H*W*32 uint8, or NULL
+void orc_set_propagation_stats(uint8_t* bad3) { g_stat_bad3 = bad3; }
 int orc_num_threads(void) {
 #if defined(_OPENMP)
     return omp_get_max_threads();

@@ -35,6 +35,8 @@ def main():
     prm = pm.PatchMatchParams(num_images=V + 1, depth_min=float(dmin), depth_max=float(dmax), max_scale=0)
     o = ob.create()
     o.set_views(cams, imgs)
+    lib.orc_set_propagation_stats.argtypes = [C.c_void_p]
+    bad3 = np.zeros((H, W, 32), np.uint8)
     death = np.full((H, W, 5), -128, np.int8)
     wmask = np.zeros((H, W), np.uint32)
     o.step(prm, 12345, pm.KIND_INIT, 0, 0, 0)
@@ -45,12 +47,15 @@ def main():
         for kind, parity in ((pm.KIND_BLACK, 0), (pm.KIND_RED, 1)):
             death[...] = -128
             lib.orc_set_refinement_stats(death.ctypes.data, wmask.ctypes.data)
+            lib.orc_set_propagation_stats(bad3.ctypes.data)
             o.step(prm, 12345, kind, it, 0, launch)
             lib.orc_set_refinement_stats(None, None)
+            lib.orc_set_propagation_stats(None)
             launch += 1
             upd = (death[..., 0] != -128)
             assert (upd == (((xx + yy) & 1) == parity))[: 2 * 16 * (((H // 2) + 15) // 16)].all()
             now = uni = comp = xl = 0.0
+            a_now = a_xl = a_lane = 0.0
             nw = 0
             lane_live = []
             for y0 in range(0, H - 7, 8):
@@ -61,6 +66,13 @@ def main():
                     if len(wm) != 64:
                         continue
                     nw += 1
+                    b3 = bad3[y0:y0 + 8, x0:x0 + 16][m].astype(np.int32)        # [64][32]
+                    fl = b3[:, 31]
+                    for v in range(V):
+                        a_now += 8
+                        alive = np.stack([((fl >> j) & 1).astype(bool) & (b3[:, v] >= j) for j in range(8)], 1)   # [64][8]
+                        a_xl += -(-int(alive.sum()) // 64)
+                        a_lane += alive.sum() / 64.0
                     for v in range(V):
                         has_w = ((wm >> v) & 1).astype(bool)                     # lanes with weight on view v
                         if not has_w.any():
@@ -72,7 +84,8 @@ def main():
                         xl += -(-int(live.sum()) // 64)
                         lane_live.append(live.sum() / 64.0)
             print(f"  iter {it} {'black' if parity == 0 else 'red  '}: now {now / nw:5.2f}  uniform-skip {uni / nw:5.2f}  lane-compacted {comp / nw:5.2f}  cross-lane-compacted {xl / nw:5.2f}"
-                  f"   (mean live steps per LANE {np.sum(lane_live) / nw:5.2f})   dead-from-start {float((death[upd] == -1).mean()):.3f}")
+                  f"   (mean live steps per LANE {np.sum(lane_live) / nw:5.2f})   dead-from-start {float((death[upd] == -1).mean()):.3f}"
+                  f"   | propagation: now {a_now / nw:5.2f}  cross-lane-compacted {a_xl / nw:5.2f}  (mean per lane {a_lane / nw:5.2f})")
 
 
 if __name__ == "__main__":
