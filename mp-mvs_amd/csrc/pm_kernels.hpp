@@ -269,20 +269,26 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
     int pos[8];
     if (kWavesPerSimd<U8> >= 3) keep_in_memory(reinterpret_cast<float*>(pos));
     uint32_t flags = 0;
+    // The 88 stored costs are read UNCONDITIONALLY, at the position clamped into the image, and a position outside the image is
+    // ignored afterwards: the loads of a region then sit in straight-line code and go out back to back.  (Loaded under their
+    // bounds test, each was its own branch with its own s_waitcnt vmcnt(0): 88 serialised round trips per pixel and launch.)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
+        float nc[12];
+#pragma unroll
+        for (int d = 0; d < kNumDirs[k]; ++d) {
+            const int nx = x + kDirs[k][d].x, ny = y + kDirs[k][d].y;
+            const int cx = nx < 0 ? 0 : (nx > W - 1 ? W - 1 : nx), cy = ny < 0 ? 0 : (ny > Hh - 1 ? Hh - 1 : ny);
+            nc[d] = S.costs[cy * W + cx];
+        }
         float best = 3.402823466e+38f;
         int bpos = 0;
 #pragma unroll
         for (int d = 0; d < kNumDirs[k]; ++d) {
             const int nx = x + kDirs[k][d].x, ny = y + kDirs[k][d].y;
-            if (nx >= 0 && ny >= 0 && nx < W && ny < Hh) {
-                const int nidx = ny * W + nx;
-                const float nc = S.costs[nidx];
-                if (best > nc) {
-                    best = nc;
-                    bpos = nidx;
-                }
+            if (nx >= 0 && ny >= 0 && nx < W && ny < Hh && best > nc[d]) {
+                best = nc[d];
+                bpos = ny * W + nx;
             }
         }
         pos[k] = bpos;
@@ -341,12 +347,12 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
     // The candidates' m vectors wait in private memory (fetched one evaluation ahead).
     float cand_m[8 * 3];
     keep_in_memory(cand_m);
+    // (read unconditionally as well -- pos is 0 where a region has no candidate -- so that the eight loads are in flight together)
+#pragma unroll
     for (int slot = 0; slot < 8; ++slot) {
-        if ((flags >> slot) & 1u) {
-            float m0, m1, m2;
-            plane_to_m(P, S.planes[pos[slot]], m0, m1, m2);
-            cand_m[3 * slot] = m0, cand_m[3 * slot + 1] = m1, cand_m[3 * slot + 2] = m2;
-        }
+        float m0, m1, m2;
+        plane_to_m(P, S.planes[pos[slot]], m0, m1, m2);
+        cand_m[3 * slot] = m0, cand_m[3 * slot + 1] = m1, cand_m[3 * slot + 2] = m2;
     }
     for (int v = 0; v < V; ++v) {
         int cn = 0;       // good count | bad count << 8   (ref .cu:834-845)
