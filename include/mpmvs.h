@@ -98,7 +98,9 @@ int mpmvs_set_views(mpmvs_ctx* ctx, int n, const mpmvs_camera* cams, const float
                     const size_t* pitch_bytes);
 
 /* CudaMemInit source depth upload for geometric consistency
- * (src/PatchMatch.cpp:1027-1050, read at :941-948); n_src == n-1 */
+ * (src/PatchMatch.cpp:1027-1050, read at :941-948); n_src == n-1.  depths[i] == NULL keeps the map of source i that an
+ * earlier call uploaded (its size must be the one stated): a caller that knows which maps changed since the last pass
+ * uploads only those. */
 int mpmvs_set_src_depths(mpmvs_ctx* ctx, int n_src, const float* const* depths, const int* widths,
                          const int* heights, const size_t* pitch_bytes);
 /* same, from dense device buffers (pointers valid on the context's device);
@@ -236,6 +238,15 @@ void mpmvs_fuse_passes(int* total, int* max_per_image);
 int mpmvs_sky_bilateral(int device, const unsigned char* bgr, const float* mask, float* out, int height, int width);
 /* device time (ms, HIP events) of the kernel of the last mpmvs_sky_bilateral call */
 float mpmvs_sky_kernel_ms(void);
+
+/* ---- host arrays ------------------------------------------------------------ */
+/* Page-locked host memory for the arrays the reference allocates with new[] in AllocatePatchMatch and
+ * CudaPlanarPriorInitialization (hostPlaneHypotheses, hostCosts, hostGeomCosts, hostPriorPlanes, hostPlaneMask;
+ * src/PatchMatch.cpp:966-972,979-982): with them the copies of mpmvs_run_get / mpmvs_get / mpmvs_set_state / mpmvs_set_prior
+ * are DMA transfers at PCIe rate and, inside mpmvs_run_get, asynchronous.  Any host memory works; this is the fast kind.
+ * Released buffers are pooled per size.  NULL on failure. */
+void* mpmvs_alloc_pinned(size_t bytes);
+void mpmvs_free_pinned(void* p);
 
 /* ---- resident texture format ---------------------------------------------- */
 /* Source images whose pixels are all integers in [0, 255] (the reference's

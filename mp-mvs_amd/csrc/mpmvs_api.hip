@@ -172,6 +172,23 @@ static hipError_t pool_free(void* p) {
     return hipFree(p);
 }
 
+// Pinned host buffers for the host arrays of the wrapper (hostPlaneHypotheses ...): hipHostMalloc takes milliseconds, the
+// wrapper allocates the same few sizes for every Problem and pass, so released buffers are kept per size (at most
+// MPMVS_PINNED_POOL_MB, default 1024).
+namespace {
+struct PinnedPool {
+    std::mutex mu;
+    std::unordered_map<void*, size_t> owner;
+    std::map<size_t, std::vector<void*>> cached;
+    size_t cached_bytes = 0;
+    size_t cap = 1024ull << 20;
+    PinnedPool() {
+        if (const char* e = std::getenv("MPMVS_PINNED_POOL_MB")) cap = (size_t)std::strtoull(e, nullptr, 10) << 20;
+    }
+};
+PinnedPool g_pinned;
+}  // namespace
+
 // scratch device buffer of a probe call: released on every return path (hipFree waits for the device)
 struct DevBuf {
     void* p = nullptr;
@@ -533,17 +550,38 @@ static int attach_depths(mpmvs_ctx* c, int n_src, const int* widths, const int* 
     return upload_problem(c);
 }
 
+// (re)allocates the map of source i when its size changes; a kept map must have the size the caller states
+static int depth_slot(mpmvs_ctx* c, int i, int w, int h, bool replace) {
+    if (w <= 0 || h <= 0) return fail(c, -2, "bad depth map");
+    const ViewDev& o = c->hP.views[i];
+    if (c->d_depth[i] && o.dw == w && o.dh == h) return 0;
+    if (!replace) return fail(c, -2, "no resident depth map of that size to keep");
+    if (c->d_depth[i]) (void)pool_free(c->d_depth[i]);
+    c->d_depth[i] = nullptr;
+    HIPCHK(c, pool_malloc(&c->d_depth[i], (size_t)w * h * 4));
+    return 0;
+}
+
 int mpmvs_set_src_depths(mpmvs_ctx* c, int n_src, const float* const* depths, const int* widths, const int* heights, const size_t* pitch_bytes) {
     if (!c) return -1;
     HIPCHK(c, enter_device(c->device));
     if (c->n_img < 2 || n_src != c->n_img - 1) return fail(c, -1, "n_src must equal the number of source views");
     (void)hipStreamSynchronize(c->stream);
-    for (float* p : c->d_depth) (void)pool_free(p);
-    c->d_depth.assign(n_src, nullptr);
+    if ((int)c->d_depth.size() != n_src) {
+        for (float* p : c->d_depth) (void)pool_free(p);
+        c->d_depth.assign(n_src, nullptr);
+        c->have_depths = false;
+    }
     for (int i = 0; i < n_src; ++i) {
-        if (widths[i] <= 0 || heights[i] <= 0 || !depths[i]) return fail(c, -2, "bad depth map");
-        HIPCHK(c, pool_malloc(&c->d_depth[i], (size_t)widths[i] * heights[i] * 4));
+        int rc = depth_slot(c, i, widths[i], heights[i], depths[i] != nullptr);
+        if (rc) {
+            c->have_depths = false;
+            return rc;
+        }
+        if (!depths[i]) continue;  // keep the map an earlier call uploaded
         const size_t pitch = pitch_bytes ? pitch_bytes[i] : (size_t)widths[i] * 4;
+        ViewDev& o = c->hP.views[i];
+        o.dw = widths[i], o.dh = heights[i];  // depth_slot compares against these
         HIPCHK(c, hipMemcpy2DAsync(c->d_depth[i], (size_t)widths[i] * 4, depths[i], pitch, (size_t)widths[i] * 4, heights[i], hipMemcpyHostToDevice, c->stream));
     }
     return attach_depths(c, n_src, widths, heights);
@@ -554,13 +592,20 @@ int mpmvs_set_src_depths_device(mpmvs_ctx* c, int n_src, const float* const* d_d
     HIPCHK(c, enter_device(c->device));
     if (c->n_img < 2 || n_src != c->n_img - 1) return fail(c, -1, "n_src must equal the number of source views");
     (void)hipStreamSynchronize(c->stream);
-    for (float* p : c->d_depth) (void)pool_free(p);
-    c->d_depth.assign(n_src, nullptr);
+    if ((int)c->d_depth.size() != n_src) {
+        for (float* p : c->d_depth) (void)pool_free(p);
+        c->d_depth.assign(n_src, nullptr);
+        c->have_depths = false;
+    }
     for (int i = 0; i < n_src; ++i) {
-        if (widths[i] <= 0 || heights[i] <= 0 || !d_depths[i]) return fail(c, -2, "bad depth map");
-        const size_t bytes = (size_t)widths[i] * heights[i] * 4;
-        HIPCHK(c, pool_malloc(&c->d_depth[i], bytes));
-        HIPCHK(c, hipMemcpyAsync(c->d_depth[i], d_depths[i], bytes, hipMemcpyDeviceToDevice, c->stream));
+        if (!d_depths[i]) return fail(c, -2, "bad depth map");
+        int rc = depth_slot(c, i, widths[i], heights[i], true);
+        if (rc) {
+            c->have_depths = false;
+            return rc;
+        }
+        c->hP.views[i].dw = widths[i], c->hP.views[i].dh = heights[i];
+        HIPCHK(c, hipMemcpyAsync(c->d_depth[i], d_depths[i], (size_t)widths[i] * heights[i] * 4, hipMemcpyDeviceToDevice, c->stream));
     }
     return attach_depths(c, n_src, widths, heights);
 }
@@ -1448,6 +1493,45 @@ int mpmvs_sky_bilateral(int device, const unsigned char* bgr, const float* mask,
     (void)pool_free(d_out);
     (void)hipStreamDestroy(st);
     return rc;
+}
+
+void* mpmvs_alloc_pinned(size_t bytes) {
+    if (bytes == 0) bytes = 4;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned.mu);
+        auto it = g_pinned.cached.find(bytes);
+        if (it != g_pinned.cached.end() && !it->second.empty()) {
+            void* p = it->second.back();
+            it->second.pop_back();
+            g_pinned.cached_bytes -= bytes;
+            return p;
+        }
+    }
+    void* p = nullptr;
+    (void)hipGetLastError();
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_pinned.mu);
+    g_pinned.owner[p] = bytes;
+    return p;
+}
+
+void mpmvs_free_pinned(void* p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned.mu);
+        auto it = g_pinned.owner.find(p);
+        if (it == g_pinned.owner.end()) return;  // not ours
+        if (g_pinned.cached_bytes + it->second <= g_pinned.cap) {
+            g_pinned.cached[it->second].push_back(p);
+            g_pinned.cached_bytes += it->second;
+            return;
+        }
+        g_pinned.owner.erase(it);
+    }
+    (void)hipHostFree(p);
 }
 
 int mpmvs_set_texture_format(mpmvs_ctx* c, int force_fp32) {

@@ -345,8 +345,14 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
     // neighbouring pixels and land close to each other in it: the later ones find their texels in the L1) instead of walking
     // through all textures once per candidate; the per-view statistics (good / bad counts, weight sum) become two scalars.
     // The candidates' m vectors wait in private memory (fetched one evaluation ahead).
+    // Where the variant has the registers, the m vectors live there and are picked by register index (s_set_gpr_idx_on): a
+    // scratch load per value sits on the same in-order vmcnt queue as the gathers and costs 2 % (fp16 texels) to 3.5 % (fp32)
+    // of the launch.  Parked in private memory only in the two variants that would otherwise spill around the evaluations.
     float cand_m[8 * 3];
-    keep_in_memory(cand_m);
+#ifndef PM_PARK_M_WHEN
+#define PM_PARK_M_WHEN (!U8 && ((PRIOR && MAXV == 8) || (GEOM && MAXV == 32)))
+#endif
+    if (PM_PARK_M_WHEN) keep_in_memory(cand_m);
     // (read unconditionally as well -- pos is 0 where a region has no candidate -- so that the eight loads are in flight together)
 #pragma unroll
     for (int slot = 0; slot < 8; ++slot) {
@@ -582,7 +588,10 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
     // owner's pixel, weight records and window statistics -- and the owner collects the costs in ascending view order, exactly
     // the sums of the uncompacted loop.  38 -> 25 evaluation rounds per wave and update on the cfg-1 scene.
     float cpl[5 * 4], tcs[5], tgs[5];
-    keep_in_memory(cpl);
+#ifndef PM_PARK_CPL_WHEN
+#define PM_PARK_CPL_WHEN true
+#endif
+    if (PM_PARK_CPL_WHEN) keep_in_memory(cpl);
     uint32_t dead = 0;
 #pragma unroll
     for (int ci = 0; ci < 5; ++ci) {

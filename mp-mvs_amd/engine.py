@@ -29,6 +29,8 @@ _EXTRA = {
     "prior_vertices": (C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
     "prior_from_triangles": (C.c_int, [_P, C.POINTER(_abi.PatchMatchParams), _P, C.c_int]),
     "get_prior": (C.c_int, [_P, _P, _P]),
+    "alloc_pinned": (C.c_void_p, [C.c_size_t]),
+    "free_pinned": (None, [C.c_void_p]),
     "eval_ncc_multi": (C.c_int, [_P, C.POINTER(_abi.PatchMatchParams), _P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_float)]),
 }
 ALL_SYMBOLS = ["mpmvs_" + n for n in list(_abi.SIGNATURES) + list(_EXTRA)] + ["mpmvs_fuse", "mpmvs_fuse_kernel_ms", "mpmvs_fuse_passes", "mpmvs_sky_bilateral", "mpmvs_sky_kernel_ms", "mpmvs_fuse_ply", "mpmvs_free"]

@@ -20,6 +20,7 @@
 #define MPMVS_HOST_PATCHMATCH_H_
 
 #include <cstdint>
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <vector>
@@ -73,14 +74,59 @@ struct Triangle {
 };
 
 // dense row-major fp32 image with `ch` interleaved channels (stands in for cv::Mat_<float>)
+//
+// `stamp` lets the device residency below recognise contents it already holds: 0 = unknown (every fresh image, and every
+// image written through at()); Seal() gives the present contents a unique stamp that travels with copies and moves.  Code
+// that writes `data` directly after sealing must reset the stamp.
 struct Image {
     int rows = 0, cols = 0, ch = 1;
+    uint64_t stamp = 0;
     std::vector<float> data;
     Image() {}
     Image(int r, int c, int channels = 1, float v = 0.0f) : rows(r), cols(c), ch(channels), data((size_t)r * c * channels, v) {}
     bool empty() const { return data.empty(); }
-    float& at(int r, int c, int k = 0) { return data[((size_t)r * cols + c) * ch + k]; }
+    float& at(int r, int c, int k = 0) {
+        stamp = 0;
+        return data[((size_t)r * cols + c) * ch + k];
+    }
     float at(int r, int c, int k = 0) const { return data[((size_t)r * cols + c) * ch + k]; }
+    void Seal();  // the contents are final until the next write: a new unique stamp
+};
+uint64_t NewImageStamp();
+
+// Host arrays of PatchMatchCUDA (the reference's `new float4[...]`, src/PatchMatch.cpp:966-972,979-982): page-locked
+// memory from the C ABI's pool, not zero-filled -- every user writes them in full before reading.
+template <class T>
+class HostArray {
+    T* p = nullptr;
+    size_t n = 0;
+    bool pinned = false;
+
+   public:
+    HostArray() {}
+    HostArray(const HostArray&) = delete;
+    HostArray& operator=(const HostArray&) = delete;
+    ~HostArray() { clear(); }
+    void allocate(size_t count) {
+        if (count == n && p) return;
+        clear();
+        p = static_cast<T*>(mpmvs_alloc_pinned(count * sizeof(T)));
+        pinned = p != nullptr;
+        if (!p) p = static_cast<T*>(std::malloc(count * sizeof(T) + 1));  // pageable fallback: slower copies, same results
+        n = count;
+    }
+    void clear() {
+        if (p && pinned) mpmvs_free_pinned(p);
+        if (p && !pinned) std::free(p);
+        p = nullptr;
+        n = 0;
+    }
+    bool empty() const { return n == 0; }
+    size_t size() const { return n; }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
 };
 
 // Device residency of one Problem between the passes of the schedule: the context with the packed textures
@@ -118,15 +164,17 @@ class PatchMatchCUDA {
     mpmvs_ctx* ctx = nullptr;  // replaces reference PatchMatch.h:95-117
     int device = 0;
     uint64_t seed = 0;
-    std::vector<float4> hostPlaneHypotheses;
-    std::vector<float> hostCosts;
-    std::vector<float> hostGeomCosts;
-    std::vector<float4> hostPriorPlanes;
-    std::vector<unsigned int> hostPlaneMask;
+    HostArray<float4> hostPlaneHypotheses;
+    HostArray<float> hostCosts;
+    HostArray<float> hostGeomCosts;
+    HostArray<float4> hostPriorPlanes;
+    HostArray<unsigned int> hostPlaneMask;
     PatchMatchParams params;
     std::string input_folder, output_folder;
     Scene* ref_scene = nullptr;     // Scenes[ID] of PatchMatchInit: owner of the device cache
     bool views_resident = false;    // the adopted context already holds this Problem's textures
+    uint64_t resident_state_stamp = 0;            // stamp of the depth / normal / cost maps whose state the context holds (0: none)
+    std::vector<uint64_t> resident_depth_stamps;  // stamps of the source depth maps the context holds
     bool host_state_valid = false;  // hostPlaneHypotheses / hostCosts mirror the device state
     bool deferred_fetch = false;    // Run() leaves its maps in HBM until the host first reads one (SetDeferredFetch)
     void check(int rc, const char* what);
@@ -167,6 +215,10 @@ class PatchMatchCUDA {
         fetch_host_state();
         return hostPlaneHypotheses.data();
     }
+    const float* GetCosts() {  // the whole hostCosts array
+        fetch_host_state();
+        return hostCosts.data();
+    }
     float GetCost(const int index);
     float GetGeomCost(const int index);
 
@@ -174,6 +226,9 @@ class PatchMatchCUDA {
     std::vector<Triangle> DelaunayTriangulation(const Rect boundRC, const std::vector<Point>& points);
     void GetTriangulateVertices(std::vector<Point>& Vertices);
 
+    // the maps with this stamp are what the device state holds now (ProcessProblem calls it with the stamp of its results):
+    // the next pass over this Problem then skips the upload of its start state
+    void NoteResidentState(uint64_t stamp) { resident_state_stamp = stamp; }
     void Release(std::vector<Scene>& Scenes, const int& ID);
 };
 

@@ -55,6 +55,8 @@ struct ProblemDeviceCache {
     int device = -1;
     std::vector<const float*> image_data;
     std::vector<Camera> cameras;
+    uint64_t state_stamp = 0;            // Image::stamp of the maps whose state (planes, costs) the context holds
+    std::vector<uint64_t> depth_stamps;  // ... of the source depth maps it holds
     size_t bytes = 0;
     static std::atomic<size_t>& held() {
         static std::atomic<size_t> h(0);
@@ -74,6 +76,11 @@ static size_t ctx_cache_cap() {
     }();
     return cap;
 }
+uint64_t NewImageStamp() {
+    static std::atomic<uint64_t> next(1);
+    return next.fetch_add(1);
+}
+void Image::Seal() { stamp = NewImageStamp(); }
 void ReleaseDeviceCaches(std::vector<Scene>& Scenes) {
     for (Scene& s : Scenes) s.device_cache.reset();
 }
@@ -194,16 +201,23 @@ void PatchMatchCUDA::AllocatePatchMatch() {
             cached->ctx = nullptr;
             ProblemDeviceCache::held() -= cached->bytes;
             views_resident = true;
+            resident_state_stamp = cached->state_stamp;
+            resident_depth_stamps = cached->depth_stamps;
         }
+    }
+    if (!views_resident) {
+        resident_state_stamp = 0;
+        resident_depth_stamps.clear();
     }
     if (!ctx) ctx = mpmvs_create(device);
     if (!ctx) {
         std::cerr << "mpmvs_create failed: " << mpmvs_last_error(nullptr) << std::endl;
         exit(EXIT_FAILURE);
     }
-    hostPlaneHypotheses.assign(wh, float4{0, 0, 0, 0});
-    hostCosts.assign(wh, 0.0f);
-    if (params.geom_consistency) hostGeomCosts.assign(wh, 0.0f);
+    // not zero-filled (the reference's new[] is not either): Run() and CudaMemInit write them in full before anything reads
+    hostPlaneHypotheses.allocate(wh);
+    hostCosts.allocate(wh);
+    if (params.geom_consistency) hostGeomCosts.allocate(wh);
 }
 
 // reference src/PatchMatch.cpp:998-1089
@@ -225,30 +239,49 @@ void PatchMatchCUDA::CudaMemInit(Scene& scene) {
             ws.push_back(d.cols);
             hs.push_back(d.rows);
         }
-        check(mpmvs_set_src_depths(ctx, num_img - 1, dptr.data(), ws.data(), hs.data(), nullptr), "mpmvs_set_src_depths");
+        // a source depth map the adopted context already holds (same sealed contents, Image::stamp) is not uploaded again:
+        // NULL keeps it (include/mpmvs.h).  The reference uploads all of them on every call (:1027-1050).
+        if (resident_depth_stamps.size() != depths.size()) resident_depth_stamps.assign(depths.size(), 0);
+        bool any = false;
+        for (size_t i = 0; i < depths.size(); ++i) {
+            if (depths[i]->stamp != 0 && depths[i]->stamp == resident_depth_stamps[i])
+                dptr[i] = nullptr;
+            else
+                any = true;
+            resident_depth_stamps[i] = depths[i]->stamp;
+        }
+        if (any) check(mpmvs_set_src_depths(ctx, num_img - 1, dptr.data(), ws.data(), hs.data(), nullptr), "mpmvs_set_src_depths");
         // previous result of this image is the start state (reference :1052-1086)
         if (scene.depth.empty() || scene.normal.empty() || scene.cost.empty()) {
             std::cout << "Can not read this depth image !" << std::endl;
             exit(0);
         }
-        const int width = scene.depth.cols, height = scene.depth.rows;
+        // ... unless the adopted context still holds exactly that state: the maps carry the stamp ProcessProblem gave its
+        // results when it left the context behind
+        const bool state_resident = resident_state_stamp != 0 && scene.depth.stamp == resident_state_stamp &&
+                                    scene.normal.stamp == resident_state_stamp && scene.cost.stamp == resident_state_stamp;
+        if (!state_resident) {
+            const Image &sn = scene.normal, &sd = scene.depth, &sc = scene.cost;
+            const int width = sd.cols, height = sd.rows;
 #pragma omp parallel for schedule(static)
-        for (int row = 0; row < height; ++row)
-            for (int col = 0; col < width; ++col) {
-                const size_t idx = (size_t)row * width + col;
-                hostPlaneHypotheses[idx] = float4{scene.normal.at(row, col, 0), scene.normal.at(row, col, 1), scene.normal.at(row, col, 2), scene.depth.at(row, col)};
-                hostCosts[idx] = scene.cost.at(row, col);
-            }
-        check(mpmvs_set_state(ctx, hostPlaneHypotheses.data(), hostCosts.data()), "mpmvs_set_state");
+            for (int row = 0; row < height; ++row)
+                for (int col = 0; col < width; ++col) {
+                    const size_t idx = (size_t)row * width + col;
+                    hostPlaneHypotheses[idx] = float4{sn.at(row, col, 0), sn.at(row, col, 1), sn.at(row, col, 2), sd.at(row, col)};
+                    hostCosts[idx] = sc.at(row, col);
+                }
+            check(mpmvs_set_state(ctx, hostPlaneHypotheses.data(), hostCosts.data()), "mpmvs_set_state");
+        }
     }
+    resident_state_stamp = 0;  // Run() changes the state; ProcessProblem notes the stamp of its results afterwards
 }
 
 // reference src/PatchMatch.cpp:978-996
 void PatchMatchCUDA::CudaPlanarPriorInitialization(const std::vector<float4>& PlaneParams, const Image& masks) {
     const int W = cameras[0].width, H = cameras[0].height;
     StageTimer tm;
-    hostPriorPlanes.resize((size_t)W * H);
-    hostPlaneMask.resize((size_t)W * H);
+    hostPriorPlanes.allocate((size_t)W * H);
+    hostPlaneMask.allocate((size_t)W * H);
     tm.lap("  prior: resize");
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < H; ++i)
@@ -287,14 +320,14 @@ void PatchMatchCUDA::Run() {
         host_state_valid = false;
         return;
     }
-    if (params.geomPlanarPrior && hostGeomCosts.empty()) hostGeomCosts.assign(hostCosts.size(), 0.0f);
+    if (params.geomPlanarPrior && hostGeomCosts.empty()) hostGeomCosts.allocate(hostCosts.size());
     check(mpmvs_run_get(ctx, &params, seed, hostPlaneHypotheses.data(), hostCosts.data(), params.geomPlanarPrior ? hostGeomCosts.data() : nullptr),
           "mpmvs_run_get");
     host_state_valid = true;
 }
 void PatchMatchCUDA::fetch_host_state() {
     if (host_state_valid) return;
-    if (hostGeomCosts.empty() && params.geomPlanarPrior) hostGeomCosts.assign(hostCosts.size(), 0.0f);
+    if (hostGeomCosts.empty() && params.geomPlanarPrior) hostGeomCosts.allocate(hostCosts.size());
     check(mpmvs_get(ctx, hostPlaneHypotheses.data(), hostCosts.data(), params.geomPlanarPrior ? hostGeomCosts.data() : nullptr), "mpmvs_get");
     host_state_valid = true;
 }
@@ -367,6 +400,8 @@ void PatchMatchCUDA::Release(std::vector<Scene>&, const int&) {
             keep->device = device;
             for (const Image* im : images) keep->image_data.push_back(im->data.data());
             keep->cameras = cameras;
+            keep->state_stamp = resident_state_stamp;
+            keep->depth_stamps = resident_depth_stamps;
             keep->bytes = bytes;
             ProblemDeviceCache::held() += bytes;
             ref_scene->device_cache = std::move(keep);
@@ -443,17 +478,24 @@ void ProcessProblem(std::vector<Scene>& Scenes, const int ID, bool geom_consiste
     out.normal = Image(height, width, 3);
     out.cost = Image(height, width, 1);
     const float4* host_planes = MP.GetPlaneHypotheses();
+    const float* host_costs = MP.GetCosts();
+    float *pd = out.depth.data.data(), *pn = out.normal.data.data(), *pc = out.cost.data.data();
 #pragma omp parallel for schedule(static)
     for (int row = 0; row < height; ++row)
         for (int col = 0; col < width; ++col) {
-            const int idx = row * width + col;
+            const size_t idx = (size_t)row * width + col;
             const float4 pl = host_planes[idx];
-            out.depth.at(row, col) = pl.w;
-            out.normal.at(row, col, 0) = pl.x;
-            out.normal.at(row, col, 1) = pl.y;
-            out.normal.at(row, col, 2) = pl.z;
-            out.cost.at(row, col) = MP.GetCost(idx);
+            pd[idx] = pl.w;
+            pn[3 * idx] = pl.x;
+            pn[3 * idx + 1] = pl.y;
+            pn[3 * idx + 2] = pl.z;
+            pc[idx] = host_costs[idx];
         }
+    // the three maps are exactly what the context holds now: one stamp for them and for the context that Release() leaves
+    // with the Scene, so that the next pass over this Problem finds its start state in HBM
+    const uint64_t stamp = NewImageStamp();
+    out.depth.stamp = out.normal.stamp = out.cost.stamp = stamp;
+    MP.NoteResidentState(stamp);
     if (!results) {
         scene.depth = std::move(out.depth);
         scene.normal = std::move(out.normal);
@@ -566,6 +608,7 @@ int mpmvs_host_run_pipeline(int device, int n, const mpmvs_camera* cams, const f
         if (i > 0 && src_depths) {
             s.depth = Image(cams[i].height, cams[i].width, 1);
             std::memcpy(s.depth.data.data(), src_depths[i - 1], s.depth.data.size() * sizeof(float));
+            s.depth.Seal();  // held fixed over the passes: uploaded once
         }
     }
     Scenes[0].estimate = true;
