@@ -23,11 +23,14 @@ collective (weak scaling); RCCL only provides the barrier and the max-reduce of 
 sharded over the ranks, the shipped schedule (photometric 3 scales -> geometric + planar prior -> geometric), ONE
 all_gather_into_tensor of the depth maps per pass over RCCL (mp-mvs_amd/schedule.py); strong scaling.
 """
+import os
+# the CPU baseline's OpenMP runtime reads these when it starts: threads stay on the core they start on, one place per core
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
 import argparse
 import ctypes
 import importlib
 import json
-import os
 import sys
 import time
 
@@ -129,8 +132,30 @@ def measured_traffic_bytes():
             # bytes (exactly half for wide coalesced streaming reads, to be doubled), other access widths are uncalibrated: this
             # kernel's HBM reads are L2 misses of 8 / 16-byte gathers plus scratch refills, so the bytes lie between the raw sum
             # (`traffic`) and the sum with FETCH_SIZE doubled (`traffic_if_fetch_doubled`)
-            best = ((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0)
+            best = ((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+                    f"profiles/{name}: FETCH_SIZE + WRITE_SIZE per k_update launch of a committed rocprofv3 --pmc run of this command (PMC cannot be read in-process)")
     return best
+
+
+def profile_valu_busy():
+    """executed-work utilisation of the committed PMC run: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), per k_update launch"""
+    pdir = os.path.join(ROOT, "profiles")
+    out = None
+    if not os.path.isdir(pdir):
+        return None
+    for name in sorted(os.listdir(pdir)):
+        if not name.endswith(".txt") or "pmc_summary" not in name:
+            continue
+        vals, kern = {}, None
+        for line in open(os.path.join(pdir, name)):
+            t = line.strip()
+            if t.startswith("k_"):
+                kern = t.split()[0]
+            elif kern == "k_update" and "avg=" in t:
+                vals[t.split()[0]] = float(t.split("avg=")[1])
+        if "SQ_ACTIVE_INST_VALU" in vals and "GRBM_GUI_ACTIVE" in vals:
+            out = {"value": round(vals["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * vals["GRBM_GUI_ACTIVE"] / 8.0), 4), "source": f"profiles/{name}"}
+    return out
 
 
 def roofline_of(upd_avg_ms, w, h, v):
@@ -162,31 +187,71 @@ def timed_runs(pm, ctx, prm, seed, steps, bufs=None):
     return time.perf_counter() - t0, upd_ms, upd_n, all_ms
 
 
+def host_cpu_facts():
+    """hardware threads this process may use, physical cores among them, and the container's CPU quota (cgroup v2 / v1)"""
+    cpus = sorted(os.sched_getaffinity(0))
+    cores = set()
+    for c in cpus:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                cores.add(f.read().strip())
+        except OSError:
+            cores.add(str(c))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    return len(cpus), len(cores), quota
+
+
 def cpu_baseline(pm, ctx, cams, imgs, prm, seed):
-    """the oracle (our CPU port; the reference has no CPU path) on the host cores: the SAME workload on the same
-    inputs (one full 1600x1200 Problem), once on every core the process may use and once on 16 threads (the share of one GPU
-    on the pool's boxes), and -- since both are then at hand -- a bit-for-bit comparison of its result with the HIP path's"""
+    """the oracle (our CPU port; the reference has no CPU path) on the host cores.  Three thread counts -- 16 (the
+    share of one GPU on the pool's boxes), the physical cores and all hardware threads, OMP_PROC_BIND=close -- are timed on a
+    bounded sample (the same Problem rendered at half the size in each direction: same views, schedule and seed; Mpix/s does
+    not depend on the image size); the best of them then runs the WHOLE workload, which gives `value` and, since both results
+    are at hand, a bit-for-bit comparison with the HIP path's."""
     from oracle import binding as ob
-    avail = len(os.sched_getaffinity(0))
-    out, op, oc = {}, None, None
-    for ncore in sorted({avail, min(16, avail)}, reverse=True):
-        ob.set_num_threads(ncore)
+    avail, physical, quota = host_cpu_facts()
+    counts = sorted({min(16, avail), physical, avail})
+    ws, hs = W // 2, H // 2
+    cs, ims, _ = load_views(pm, ws, hs, problem_centers(pm, V), f"p{V}")
+    ims = [np.rint(im).astype(np.float32) for im in ims]
+    dmin, dmax = pm.synth.kernel_depth_range(cs[0])
+    prm_s = pm.PatchMatchParams(num_images=V + 1, depth_min=float(dmin), depth_max=float(dmax), max_scale=0, max_iterations=ITERS)
+    sample = {}
+    for n in counts:
+        ob.set_num_threads(n)
         o = ob.create()
-        o.set_views(cams, imgs)
+        o.set_views(cs, ims)
         t0 = time.perf_counter()
-        o.run(prm, seed)
-        dt = time.perf_counter() - t0
-        op, oc = o.get()
-        out[ncore] = (W * H / dt / 1e6, dt)
+        o.run(prm_s, seed)
+        sample[n] = ws * hs / (time.perf_counter() - t0) / 1e6
+    best = max(sample, key=sample.get)
+    ob.set_num_threads(best)
+    o = ob.create()
+    o.set_views(cams, imgs)
+    t0 = time.perf_counter()
+    o.run(prm, seed)
+    dt = time.perf_counter() - t0
+    op, oc = o.get()
     ctx.run(prm, seed)             # untimed
     gp, gc = ctx.get()
-    res = {"value": round(out[avail][0], 5), "unit": "Mpix/s", "cores": avail, "kind": "port",
-           "sample": f"the whole workload: one {W}x{H} Problem, {V} src views, same inputs, seed and Run() schedule, OpenMP oracle on all {avail} "
-                     f"hardware threads of the box (nproc {os.cpu_count()}), {out[avail][1]:.1f} s",
-           "hip_result_bit_identical": bool(np.array_equal(op, gp) and np.array_equal(oc, gc))}
-    if min(16, avail) in out and avail != min(16, avail):
-        res["value_16_threads"] = round(out[min(16, avail)][0], 5)
-    return res
+    return {"value": round(W * H / dt / 1e6, 5), "unit": "Mpix/s", "cores": best, "kind": "port",
+            "sample": f"thread count chosen on a bounded sample (the same Problem at {ws}x{hs}: {', '.join(f'{n} threads {v:.4f} Mpix/s' for n, v in sample.items())}); "
+                      f"`value` = the whole workload (one {W}x{H} Problem, {V} src views, same inputs, seed and Run() schedule) on {best} threads, {dt:.1f} s; "
+                      f"OpenMP oracle, OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}; host: {avail} hardware threads / {physical} physical cores usable, "
+                      f"container CPU quota {'none' if quota is None else f'{quota:g} CPUs'}",
+            "threads_tried_Mpix_per_s": {str(n): round(v, 5) for n, v in sample.items()},
+            "hip_result_bit_identical": bool(np.array_equal(op, gp) and np.array_equal(oc, gc))}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -262,6 +327,15 @@ def secondary(pm, engine, dev_index, cams, imgs_f32, gts, prm, args):
         if ntri:
             out[name]["prior_triangles"] = int(ntri)
     del ctx
+    # configs[3] through the C++ mirror of the reference's interface (PatchMatchCUDA / ProcessProblem, mp-mvs_amd/host): what a
+    # user of the reference's API gets, host arrays and per-pass hand-over included
+    best = None
+    for rep in range(2):
+        t0 = time.perf_counter()
+        hostlib.run_pipeline(dev_index, cams, imgs_u8, 2, 2, True, True, 5 + rep, src_depths)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    out["cfg3"]["via_process_problem_mirror_s"] = round(best, 4)
     # -- cfg 1 with non-integer images: the fp32 texture format (what every rescaled image takes)
     ctx = engine.create(dev_index)
     ctx.set_views(cams, imgs_f32)
@@ -466,13 +540,19 @@ def main():
             "dtype": "f32",
             "data": "synthetic, seeded height-field scene; images " + ("rounded to 8 bits like the reference's imread input" if quantize else "non-integer fp32") + f"; resident texture format {ctx.texture_format()}",
             "config": {"workload": "configs[1]: 1 ref + 8 src views, 1600x1200, single-scale, photometric only, 3 red/black iterations, one Problem per GPU per step; "
-                                   "a step = Run() incl. its device-to-host copies of planes + costs, inputs resident",
+                                   "a step = Run() incl. its device-to-host copies of planes + costs; the 9 images are resident in HBM when the timed region "
+                                   "starts (bench contract), i.e. the image upload (H2D) is EXCLUDED from `value` -- SURVEY 8(d)'s wording of the metric, "
+                                   "upload + Run() + D2H per step, is `with_h2d_value` in this line",
                        "width": W, "height": H, "src_views": V, "max_scale": 0, "iterations": ITERS},
+            "comparable_across_rounds": "`value` (Run() + D2H) is the headline of rounds 2 and 3; `resident_value` (kernels only) was round 1's",
             "resident_value": round(world * W * H * args.steps / dt_res / 1e6, 3),
             "with_h2d_value": round(W * H * n_h2d / dt_h2d / 1e6, 3),
             "roofline": {
                 "kernel": "k_update<photometric> (BlackPixelUpdate/RedPixelUpdate)",
                 "bound": "valu_fp32",
+                "frac_is": "algorithmic-equivalent rate (SURVEY 8d's nominal flop / measured time / peak), NOT executed-VALU utilisation: see `note` and "
+                           "`valu_busy_from_profile`",
+                "valu_busy_from_profile": profile_valu_busy(),
                 "achieved": round(tflops, 3),
                 "peak": PEAK_VALU_TFLOPS,
                 "unit": "TFLOP/s",
@@ -480,8 +560,9 @@ def main():
                 "note": "achieved = SURVEY 8d's ALGORITHMIC flop per launch (14 hypotheses x 8 views x 2144 flop per pixel of one colour) / measured launch time; the "
                         "kernel executes roughly half of that (bilateral weights and reference moments once per pixel, homography as 9 fmas, one reciprocal per six taps, "
                         "zero-weight views skipped): it is an algorithmic-equivalent rate, not the VALU utilisation (that is in profiles/: SQ_ACTIVE_INST_VALU)",
-                "traffic": (measured_traffic_bytes() or (None, None))[0],
-                "traffic_if_fetch_doubled": (measured_traffic_bytes() or (None, None))[1],
+                "traffic": (measured_traffic_bytes() or (None, None, None))[0],
+                "traffic_if_fetch_doubled": (measured_traffic_bytes() or (None, None, None))[1],
+                "traffic_source": (measured_traffic_bytes() or (None, None, None))[2],
                 "avg_launch_ms": round(upd_avg_ms, 4),
                 "launches_timed": upd_n,
                 "algorithmic_flop_per_launch": flops_per_launch,

@@ -1079,28 +1079,36 @@ int step(Ctx& c, const Params& prm, uint64_t seed, int kind, int iter, int scale
     if (rc) return rc;
     const int W = c.W, H = c.H;
     const int ylim = checker_ylimit(H);
+    // tasks of one row segment (kTaskW pixels): with whole rows as tasks a 1200-row image keeps only a few tasks per thread
+    // on a many-core host and the slowest thread decides (the pixels are independent within a launch: any partition gives
+    // the same result)
+    constexpr int kTaskW = 128;
+    const int ntx = (W + kTaskW - 1) / kTaskW;
     if (kind == kInit || kind == kDepthNormal) {
-#pragma omp parallel for schedule(dynamic, 2)
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
         for (int y = 0; y < H; ++y)
-            for (int x = 0; x < W; ++x) {
-                if (kind == kInit)
-                    init_pixel(c, prm, seed, launch, scale, x, y);
-                else
-                    depth_normal_pixel(c, x, y);
-            }
+            for (int tx = 0; tx < ntx; ++tx)
+                for (int x = tx * kTaskW; x < W && x < (tx + 1) * kTaskW; ++x) {
+                    if (kind == kInit)
+                        init_pixel(c, prm, seed, launch, scale, x, y);
+                    else
+                        depth_normal_pixel(c, x, y);
+                }
         return 0;
     }
     const int parity = (kind == kBlack || kind == kFilterBlack) ? 0 : 1;
     const bool upd = (kind == kBlack || kind == kRed);
     if (!upd && kind != kFilterBlack && kind != kFilterRed) { c.err = "bad kernel kind"; return -6; }
-#pragma omp parallel for schedule(dynamic, 2)
-    for (int y = 0; y < (H < ylim ? H : ylim); ++y)
-        for (int x = ((y + parity) & 1); x < W; x += 2) {
-            if (upd)
-                update_pixel(c, prm, seed, launch, iter, scale, x, y);
-            else
-                filter_pixel(c, x, y);
-        }
+    const int rows = H < ylim ? H : ylim;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int y = 0; y < rows; ++y)
+        for (int tx = 0; tx < ntx; ++tx)
+            for (int x = tx * kTaskW + ((y + parity) & 1); x < W && x < (tx + 1) * kTaskW; x += 2) {  // kTaskW is even
+                if (upd)
+                    update_pixel(c, prm, seed, launch, iter, scale, x, y);
+                else
+                    filter_pixel(c, x, y);
+            }
     return 0;
 }
 

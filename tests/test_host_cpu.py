@@ -446,3 +446,20 @@ def test_pair_list_drops_ids_that_do_not_exist(hostlib, tmp_path):
     (tmp_path / "pair.txt").write_text("3\n0\n2 1 10.0 7 9.0\n1\n3 0 5.0 2 4.0 -3 8.0\n2\n1 1 0.0\n")
     got = hostlib.sample_list(str(tmp_path))
     assert got == [(True, 0, [0, 1]), (True, 1, [1, 0, 2]), (True, 2, [2])]
+
+
+def test_resize_linear_equals_independent_fixture(hostlib):
+    """ResizeLinear + the target-size rule of PatchMatchInit's "Adjust image scale" (reference src/PatchMatch.cpp:893-925)
+    against tests/golden/resize_golden_v1.npz, which tests/golden/make_resize_golden.py computed without this repository
+    (torch's bilinear interpolation, align_corners=False, no antialias = cv::resize INTER_LINEAR's geometry, in float64).
+    Tolerance: 1e-5 of the 0..255 range (fp32 interpolation against float64 rounded once)."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resize_golden_v1.npz"))
+    for k in range(int(z["n"])):
+        src, want, mx = z[f"src{k}"], z[f"dst{k}"], int(z[f"max{k}"])
+        rows, cols = src.shape
+        f = min(np.float32(mx) / np.float32(cols), np.float32(mx) / np.float32(rows))
+        new_cols, new_rows = int(np.floor(np.float32(cols) * f + np.float32(0.5))), int(np.floor(np.float32(rows) * f + np.float32(0.5)))
+        assert (new_rows, new_cols) == want.shape
+        got = hostlib.resize_linear(src, new_cols, new_rows)
+        err = np.abs(got.astype(np.float64) - want.astype(np.float64)).max()
+        assert err <= 255.0 * 1e-5, f"case {k}: max |difference| {err}"
