@@ -347,7 +347,8 @@ void ProcessProblem(const std::string& input_folder, const std::string& output_f
 // Jacobi pass schedule with worker threads (see scene_io.h)
 // ---------------------------------------------------------------------------
 int RunFolderJacobi(const std::string& input_folder, int max_src, int max_image_size, int geom_iterations, bool planar_prior,
-                    bool geomPlanarPrior, int max_scale, uint64_t seed, const std::vector<int>& devices, int workers) {
+                    bool geomPlanarPrior, int max_scale, uint64_t seed, const std::vector<int>& devices, int workers,
+                    std::vector<ProblemResult>* in_memory) {
     std::vector<Scene> Scenes;
     GenerateSampleList(input_folder, max_src, max_image_size > 0 ? max_image_size : 3200, Scenes);
     const int n = (int)Scenes.size();
@@ -391,6 +392,7 @@ int RunFolderJacobi(const std::string& input_folder, int max_src, int max_image_
                 const int i = todo[k];
                 const int device = devices[k % devices.size()];  // fixed per Problem: its context stays resident there between passes
                 ProcessProblem(Scenes, i, geom, pp, pass_seed + (uint64_t)i, device, max_scale, &results[i]);
+                if (in_memory) continue;  // the caller takes the final maps from memory: no files
                 const std::string folder = out + "/2333_" + id8(Scenes[i].refID);
                 mkdir(folder.c_str(), 0777);
                 writeDepthDmb(folder + "/depths.dmb", results[i].depth);
@@ -411,6 +413,14 @@ int RunFolderJacobi(const std::string& input_folder, int max_src, int max_image_
     };
     run_pass(false, !geomPlanarPrior && planar_prior, seed);
     for (int g = 0; g < geom_iterations; ++g) run_pass(true, geomPlanarPrior && g != geom_iterations - 1, seed + 100003ull * (g + 1));
+    if (in_memory) {
+        in_memory->assign(n, ProblemResult());
+        for (int i : todo) {
+            (*in_memory)[i].depth = std::move(Scenes[i].depth);
+            (*in_memory)[i].normal = std::move(Scenes[i].normal);
+            (*in_memory)[i].cost = std::move(Scenes[i].cost);
+        }
+    }
     return (int)todo.size();
 }
 
@@ -691,6 +701,24 @@ int mpmvs_host_run_folder_jacobi(const char* input_folder, const int* devices, i
                                  int planar_prior, int geomPlanarPrior, int max_scale, uint64_t seed, int max_image_size) {
     std::vector<int> dev(devices && n_devices > 0 ? std::vector<int>(devices, devices + n_devices) : std::vector<int>{0});
     return RunFolderJacobi(input_folder, max_src, max_image_size, geom_iterations, planar_prior != 0, geomPlanarPrior != 0, max_scale, seed, dev, workers);
+}
+// the same without result files: the final maps of image i go to depth_out[i] (H*W), normal_out[i] (H*W*3), cost_out[i]
+// (H*W) for i < n_out (NULL entries are skipped); sizes are the caller's to know (the images' own, shrunk to max_image_size)
+int mpmvs_host_run_folder_jacobi_mem(const char* input_folder, const int* devices, int n_devices, int workers, int max_src, int geom_iterations,
+                                     int planar_prior, int geomPlanarPrior, int max_scale, uint64_t seed, int max_image_size,
+                                     float* const* depth_out, float* const* normal_out, float* const* cost_out, int n_out) {
+    std::vector<int> dev(devices && n_devices > 0 ? std::vector<int>(devices, devices + n_devices) : std::vector<int>{0});
+    std::vector<ProblemResult> res;
+    const int rc = RunFolderJacobi(input_folder, max_src, max_image_size, geom_iterations, planar_prior != 0, geomPlanarPrior != 0, max_scale, seed, dev,
+                                   workers, &res);
+    if (rc < 0) return rc;
+    for (int i = 0; i < n_out && i < (int)res.size(); ++i) {
+        if (res[i].depth.empty()) continue;
+        if (depth_out && depth_out[i]) std::memcpy(depth_out[i], res[i].depth.data.data(), res[i].depth.data.size() * sizeof(float));
+        if (normal_out && normal_out[i]) std::memcpy(normal_out[i], res[i].normal.data.data(), res[i].normal.data.size() * sizeof(float));
+        if (cost_out && cost_out[i]) std::memcpy(cost_out[i], res[i].cost.data.data(), res[i].cost.data.size() * sizeof(float));
+    }
+    return rc;
 }
 int mpmvs_host_run_folder(const char* input_folder, int device, int max_src, int geom_iterations, int planar_prior,
                           int geomPlanarPrior, int max_scale, uint64_t seed, int max_image_size) {

@@ -53,8 +53,10 @@ int RefineSkyMasks(const std::string& input_folder, const std::vector<Scene>& Sc
 // independent and are processed by `workers` host threads dealt round-robin to `devices` -- the Delaunay / file work of
 // one Problem overlaps the kernels of others, and several GPUs are used from one process.  Results do not depend on
 // workers or devices, and equal SceneScheduler's (mp-mvs_amd/schedule.py).  Writes the same depths/normals/costs.dmb files.
+// in_memory (optional): no result files are written; the final maps of every estimated image are handed over instead.
 int RunFolderJacobi(const std::string& input_folder, int max_src, int max_image_size, int geom_iterations, bool planar_prior,
-                    bool geomPlanarPrior, int max_scale, uint64_t seed, const std::vector<int>& devices, int workers);
+                    bool geomPlanarPrior, int max_scale, uint64_t seed, const std::vector<int>& devices, int workers,
+                    std::vector<ProblemResult>* in_memory = nullptr);
 void ProcessProblem(const std::string& input_folder, const std::string& output_folder, std::vector<Scene>& Scenes, const int ID,
                     bool geom_consistency, bool planar_prior, uint64_t seed = 0, int device = 0, int max_scale = 2);
 

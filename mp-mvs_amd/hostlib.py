@@ -231,6 +231,29 @@ def run_folder_jacobi(folder, devices=(0,), workers=3, max_src=20, geom_iteratio
     return rc
 
 
+def run_folder_jacobi_in_memory(folder, n, height, width, devices=(0,), workers=3, max_src=20, geom_iterations=2, planar_prior=True, geom_planar_prior=True,
+                                max_scale=2, seed=12345, max_image_size=3200):
+    """run_folder_jacobi without result files: returns (depths [n][H][W], normals [n][H][W][3], costs [n][H][W]) of the last pass"""
+    lib = load()
+    dev = (C.c_int * len(devices))(*devices)
+    depth = np.zeros((n, height, width), np.float32)
+    normal = np.zeros((n, height, width, 3), np.float32)
+    cost = np.zeros((n, height, width), np.float32)
+    FP = C.POINTER(C.c_float)
+    dp = (FP * n)(*[depth[i].ctypes.data_as(FP) for i in range(n)])
+    np_ = (FP * n)(*[normal[i].ctypes.data_as(FP) for i in range(n)])
+    cp = (FP * n)(*[cost[i].ctypes.data_as(FP) for i in range(n)])
+    fn = lib.mpmvs_host_run_folder_jacobi_mem
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.POINTER(FP), C.POINTER(FP),
+                   C.POINTER(FP), C.c_int]
+    rc = fn(str(folder).encode(), dev, len(devices), workers, max_src, geom_iterations, 1 if planar_prior else 0, 1 if geom_planar_prior else 0, max_scale, seed,
+            max_image_size, dp, np_, cp, n)
+    if rc < 0:
+        raise RuntimeError(f"run_folder_jacobi (in memory) failed ({rc})")
+    return depth, normal, cost
+
+
 def write_dataset(folder, cams, images, sources, scores=None, fmt="pgm", jpeg_options=None):
     """a scene in the reference's input layout: images/%08d.<fmt>, cams/%08d_cam.txt
     (MVSNet style, reference src/PatchMatch.cpp:109-143), pair.txt (reference :67-107).

@@ -126,6 +126,24 @@ def make_scene(width, height, centers, seed=SCENE_SEED, rot_deg=2.0, depth_min=3
     return sc
 
 
+def scene_cameras(width, height, centers, seed=SCENE_SEED, rot_deg=2.0, depth_min=3.0, depth_max=8.0, focal_jitter=0.0):
+    """the cameras make_scene gives the views at `centers` (same random draws, same order), without rendering anything"""
+    rng = np.random.default_rng(seed)
+    K = np.array([[0.9 * width, 0, width / 2.0], [0, 0.9 * width, height / 2.0], [0, 0, 1.0]])
+    cams = []
+    for Cc in np.asarray(centers, np.float64):
+        R = _small_rotation(rng, rot_deg)
+        Kv = K.copy()
+        if focal_jitter > 0:
+            f = rng.uniform(1.0 - focal_jitter, 1.0 + focal_jitter, 2)
+            Kv[0, 0] *= f[0]
+            Kv[1, 1] *= f[1]
+            Kv[0, 2] += rng.uniform(-0.05, 0.05) * width
+            Kv[1, 2] += rng.uniform(-0.05, 0.05) * height
+        cams.append(make_camera(Kv, R, -R @ Cc, height, width, depth_min, depth_max))
+    return cams
+
+
 # source-view order around the centre of a 3x3 grid: nearest first
 _RING = [(1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (-1, -1), (1, -1), (-1, 1)]
 

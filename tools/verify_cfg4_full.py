@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""configs[4] at full size on ONE MI355X, two independent drivers of the same Jacobi schedule compared bit for bit:
+
+  * SceneScheduler(device_tensors=True)  -- Python, what `bench.py --workload cfg4` times: contexts resident, depth maps
+    exchanged in HBM (export -> gathered buffer -> device-to-device copies), planar prior built on the device;
+  * RunFolderJacobi                      -- C++ (mp-mvs_amd/host), the same 64 Problems read from a dataset folder
+    (images/*.pgm, cams/*_cam.txt, pair.txt), worker threads, maps handed from pass to pass on the host.
+
+64 reference-image Problems (8x8 camera grid, 8 nearest neighbours as sources), 1600x1200, shipped schedule (photometric 3 scales
+-> geometric + planar prior -> geometric).  Prints one JSON line (kept as profiles/r03_cfg4_1gpu.json).
+usage: python tools/verify_cfg4_full.py [--grid 8] [--size 1600x1200] [--workers 6]"""
+import argparse
+import importlib
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _render(args):
+    import importlib as il
+    pm = il.import_module("mp-mvs_amd")
+    w, h, centers, i = args
+    v = pm.synth.make_scene(w, h, centers, quantize=True, only={i}).views[i]
+    return i, v.image, v.gt_depth
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--grid", type=int, default=8)
+    ap.add_argument("--size", default="1600x1200")
+    ap.add_argument("--workers", type=int, default=6)
+    ap.add_argument("--seed", type=int, default=12345)
+    args = ap.parse_args()
+    import torch  # noqa: F401  (one HIP runtime for torch and the library)
+    pm = importlib.import_module("mp-mvs_amd")
+    engine = importlib.import_module("mp-mvs_amd.engine")
+    hostlib = importlib.import_module("mp-mvs_amd.hostlib")
+    sched = importlib.import_module("mp-mvs_amd.schedule")
+    W, H = (int(v) for v in args.size.lower().split("x"))
+    g = args.grid
+    n = g * g
+    centers = [((i - (g - 1) / 2.0) * 0.15, (j - (g - 1) / 2.0) * 0.15, 0.0) for j in range(g) for i in range(g)]
+    t0 = time.perf_counter()
+    from concurrent.futures import ProcessPoolExecutor
+    imgs, gts = [None] * n, [None] * n
+    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
+        for i, im, gt in pool.map(_render, [(W, H, centers, i) for i in range(n)]):
+            imgs[i], gts[i] = im, gt
+    t_render = time.perf_counter() - t0
+    neigh = []
+    for j in range(g):
+        for i in range(g):
+            cand = sorted(((ii - i) ** 2 + (jj - j) ** 2, jj * g + ii) for jj in range(g) for ii in range(g) if (ii, jj) != (i, j))
+            neigh.append([c[1] for c in cand[:8]])
+    folder = tempfile.mkdtemp(prefix="mpmvs_cfg4_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        hostlib.write_dataset(folder, pm.synth.scene_cameras(W, H, centers), imgs, neigh)
+        # both drivers work from the cameras as the files hold them (ReadCamera recomputes C = -R^T t in fp32)
+        file_cams = []
+        for i in range(n):
+            c = hostlib.read_camera(os.path.join(folder, "cams", f"{i:08d}_cam.txt"))
+            c.height, c.width = H, W
+            file_cams.append(c)
+        # -- driver 1: the scheduler of bench.py --workload cfg4
+        s = sched.SceneScheduler(file_cams, imgs, neigh, lambda: engine.create(0), device_tensors=True, max_scale=2, workers=args.workers)
+        s.fetch_results = False
+        s.timing = []
+        t0 = time.perf_counter()
+        s.run(seed=args.seed)
+        t_sched = time.perf_counter() - t0
+        res = s.fetch()
+        passes = list(s.timing)
+        del s
+        # -- driver 2: the C++ folder pipeline, results in memory
+        t0 = time.perf_counter()
+        depth, normal, cost = hostlib.run_folder_jacobi_in_memory(folder, n, H, W, devices=(0,), workers=args.workers, geom_iterations=2, planar_prior=True,
+                                                                  geom_planar_prior=True, max_scale=2, seed=args.seed)
+        t_folder = time.perf_counter() - t0
+    finally:
+        shutil.rmtree(folder, ignore_errors=True)
+    same = [bool(np.array_equal(res[i][0][..., 3], depth[i]) and np.array_equal(res[i][0][..., :3], normal[i]) and np.array_equal(res[i][1], cost[i])) for i in range(n)]
+    acc = [float((np.abs(res[i][0][..., 3] - gts[i]) / gts[i] < 0.01).mean()) for i in range(n)]
+    print(json.dumps({"workload": f"configs[4] on one MI355X: {n} Problems ({g}x{g} camera grid, 8 nearest neighbours), {W}x{H}, shipped schedule, Jacobi",
+                      "problems": n, "scheduler_device_exchange_s": round(t_sched, 3), "scheduler_Mpix_per_s": round(n * W * H / t_sched / 1e6, 2),
+                      "folder_jacobi_cpp_s": round(t_folder, 3), "host_threads": args.workers, "passes": passes,
+                      "bit_identical_problems": int(sum(same)), "all_bit_identical": bool(all(same)),
+                      "within_1pct_of_gt_mean": round(float(np.mean(acc)), 4), "render_s": round(t_render, 1)}), flush=True)
+    return 0 if all(same) else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
