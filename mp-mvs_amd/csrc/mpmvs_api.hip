@@ -1095,27 +1095,63 @@ int mpmvs_prior_from_triangles(mpmvs_ctx* c, const mpmvs_params* p, const int* t
     HIPCHK(c, enter_device(c->device));
     if (!c->S.planes) return fail(c, -1, "set_views first");
     const int W = c->W, H = c->H;
-    for (int i = 0; i < 6 * n; i += 2)
-        if (tri_xy[i] < 0 || tri_xy[i] >= W || tri_xy[i + 1] < 0 || tri_xy[i + 1] >= H) return fail(c, -2, "triangle vertex outside the image");
+    // vertex check and task table in one parallel sweep: 64 consecutive p-rows of one triangle per wave (pm_prior.hpp); a
+    // triangle of longest edge L has at most floor(L) + 2 rows (the accumulated p passes 1 after L + 1 steps; the kernel's own
+    // p < 1 test is what decides).  Chunks of triangles are counted, their task ranges follow by a prefix sum, then filled:
+    // the table is the one the sequential loop would build.
     const size_t wh = (size_t)W * H;
-    if (!c->d_prior) HIPCHK(c, pool_malloc(&c->d_prior, wh * 16));
-    if (!c->d_mask) HIPCHK(c, pool_malloc(&c->d_mask, wh * 4));
-    // task table: 64 consecutive p-rows of one triangle per wave (pm_prior.hpp); a triangle of longest edge L has at most
-    // floor(L) + 2 rows (the accumulated p passes 1 after L + 1 steps; the kernel's own p < 1 test is what decides)
-    std::vector<int> task_tri, task_row0;
-    task_tri.reserve((size_t)n + 1024);
-    task_row0.reserve((size_t)n + 1024);
-    for (int t = 0; t < n; ++t) {
-        const int* v = tri_xy + 6 * t;
+    auto rows_of = [&](int t) {
+        const int* v = tri_xy + 6 * (size_t)t;
         const long long e01 = (long long)(v[0] - v[2]) * (v[0] - v[2]) + (long long)(v[1] - v[3]) * (v[1] - v[3]);
         const long long e02 = (long long)(v[0] - v[4]) * (v[0] - v[4]) + (long long)(v[1] - v[5]) * (v[1] - v[5]);
         const long long e12 = (long long)(v[2] - v[4]) * (v[2] - v[4]) + (long long)(v[3] - v[5]) * (v[3] - v[5]);
-        const int rows = (int)std::sqrt((double)std::max(e01, std::max(e02, e12))) + 3;
-        for (int r0 = 0; r0 < rows; r0 += 64) {
-            task_tri.push_back(t);
-            task_row0.push_back(r0);
+        return (int)std::sqrt((double)std::max(e01, std::max(e02, e12))) + 3;
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nchunks = n >= 65536 ? (int)std::max(1u, std::min(8u, hw ? hw : 1u)) : 1;
+    std::vector<size_t> chunk_tasks((size_t)nchunks + 1, 0);
+    std::atomic<bool> inside(true);
+    auto chunk_range = [&](int ch, int& t0, int& t1) {
+        t0 = (int)((long long)n * ch / nchunks);
+        t1 = (int)((long long)n * (ch + 1) / nchunks);
+    };
+    auto in_chunks = [&](auto&& fn) {
+        std::vector<std::thread> pool;
+        for (int ch = 1; ch < nchunks; ++ch) pool.emplace_back(fn, ch);
+        fn(0);
+        for (std::thread& t : pool) t.join();
+    };
+    in_chunks([&](int ch) {
+        int t0, t1;
+        chunk_range(ch, t0, t1);
+        size_t k = 0;
+        bool ok = true;
+        for (int t = t0; t < t1; ++t) {
+            const int* v = tri_xy + 6 * (size_t)t;
+            for (int i = 0; i < 6; i += 2) ok &= v[i] >= 0 && v[i] < W && v[i + 1] >= 0 && v[i + 1] < H;
+            k += (size_t)(rows_of(t) + 63) / 64;
         }
-    }
+        chunk_tasks[(size_t)ch + 1] = k;
+        if (!ok) inside = false;
+    });
+    if (!inside) return fail(c, -2, "triangle vertex outside the image");
+    for (int k = 0; k < nchunks; ++k) chunk_tasks[(size_t)k + 1] += chunk_tasks[(size_t)k];
+    if (chunk_tasks.back() > 0x7fffffffull) return fail(c, -2, "too many raster tasks");
+    if (!c->d_prior) HIPCHK(c, pool_malloc(&c->d_prior, wh * 16));
+    if (!c->d_mask) HIPCHK(c, pool_malloc(&c->d_mask, wh * 4));
+    std::vector<int> task_tri(chunk_tasks.back()), task_row0(chunk_tasks.back());
+    in_chunks([&](int ch) {
+        int t0, t1;
+        chunk_range(ch, t0, t1);
+        size_t k = chunk_tasks[(size_t)ch];
+        for (int t = t0; t < t1; ++t) {
+            const int rows = rows_of(t);
+            for (int r0 = 0; r0 < rows; r0 += 64) {
+                task_tri[k] = t;
+                task_row0[k++] = r0;
+            }
+        }
+    });
     const int n_tasks = (int)task_tri.size();
     PoolBuf d_tri, d_pl, d_tt, d_tr;
     int rc = 0;

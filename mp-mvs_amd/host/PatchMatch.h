@@ -58,8 +58,9 @@ struct PatchMatchParams : mpmvs_params {
 };
 
 struct Point {
-    int x = 0, y = 0;
-    Point() {}
+    int x, y;
+    Point() {}  // deliberately writes nothing (like cv::Point's storage in a resized vector would not be, but a vector of half a
+                // million triangles is then allocated without a serial zero-fill); every use assigns before it reads
     Point(int x_, int y_) : x(x_), y(y_) {}
 };
 struct Rect {

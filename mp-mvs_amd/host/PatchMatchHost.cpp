@@ -298,11 +298,26 @@ void PatchMatchCUDA::CudaPlanarPriorInitialization(const std::vector<float4>& Pl
 
 // reference src/PatchMatch.cpp:554-595 + :978-996 on the device
 void PatchMatchCUDA::CudaPlanarPriorInitialization(const std::vector<Triangle>& triangles) {
+    static_assert(sizeof(Triangle) == 6 * sizeof(int), "a Triangle is six ints: x1 y1 x2 y2 x3 y3");
     const Rect imageRC{0, 0, cameras[0].width, cameras[0].height};
+    // reference :555 keeps the triangles whose three vertices lie inside the image.  A triangulation of the image's own
+    // vertices has no others, so the list normally goes to the device as it stands (no copy); the filtered copy is the
+    // fallback for a caller's own triangle list
+    const size_t n = triangles.size();
+    bool all_inside = true;
+#pragma omp parallel for schedule(static) reduction(&& : all_inside)
+    for (long i = 0; i < (long)n; ++i) {
+        const Triangle& t = triangles[(size_t)i];
+        all_inside = all_inside && imageRC.contains(t.pt1) && imageRC.contains(t.pt2) && imageRC.contains(t.pt3);
+    }
+    if (all_inside) {
+        check(mpmvs_prior_from_triangles(ctx, &params, reinterpret_cast<const int*>(triangles.data()), (int)n), "mpmvs_prior_from_triangles");
+        return;
+    }
     std::vector<int> tri_xy;
-    tri_xy.reserve(triangles.size() * 6);
+    tri_xy.reserve(n * 6);
     for (const Triangle& t : triangles)
-        if (imageRC.contains(t.pt1) && imageRC.contains(t.pt2) && imageRC.contains(t.pt3)) {  // reference :555
+        if (imageRC.contains(t.pt1) && imageRC.contains(t.pt2) && imageRC.contains(t.pt3)) {
             const int v[6] = {t.pt1.x, t.pt1.y, t.pt2.x, t.pt2.y, t.pt3.x, t.pt3.y};
             tri_xy.insert(tri_xy.end(), v, v + 6);
         }

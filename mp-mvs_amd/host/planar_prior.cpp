@@ -24,8 +24,10 @@
 #include <sched.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <thread>
 #include <vector>
@@ -106,7 +108,10 @@ void TriangulateVertices(int width, int height, const float* costs, const float*
         for (int x0 = 0; x0 < width; x0 += CellPicker::kCell) {
             const int x1 = std::min(width, x0 + CellPicker::kCell), y1 = std::min(height, y0 + CellPicker::kCell);
             if (geomPlanarPrior) {
-                Point p[3];
+                // (0, 0) like the reference's `std::vector<cv::Point> points(3)` (ref :812): where the cell's threshold exceeds
+                // the initial 2.0 -- costs of a geometric Run() reach 2.6, and the divisor of the first cells is small -- the
+                // reference pushes these never-assigned points, i.e. pixel (0, 0) becomes a vertex
+                Point p[3] = {Point(0, 0), Point(0, 0), Point(0, 0)};
                 const int n = pick.best_three(x0, y0, x1, y1, p);
                 Vertices.insert(Vertices.end(), p, p + n);
             } else {
@@ -463,9 +468,23 @@ struct Triangulation {
     }
     int chunk_begin(int c) const { return (int)((long long)E * c / chunks); }
 
+    // Every chunk of half-edges lists its triangles ONCE into a staging buffer of its own (first touched by the thread that
+    // fills it); write() then only copies.  (Until round 3 the faces were walked twice, once to count and once to write:
+    // two pointer-chasing passes over 6 n half-edges.)
+    std::vector<std::unique_ptr<Triangle[]>> staged;
+
     bool run(const Point* points, size_t count) {
         bool wide = false;
+        const bool timing = std::getenv("MPMVS_HOST_TIMING") != nullptr;
+        auto t_prev = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (!timing) return;
+            const auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[mpmvs_host]     delaunay: %-18s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+            t_prev = now;
+        };
         if (!DistinctPoints(points, count, pts, wide)) return false;
+        lap("distinct points");
         const int n = (int)pts.size();
         first.assign(2, 0);
         if (n < 3) return true;
@@ -480,20 +499,32 @@ struct Triangulation {
         while ((2 << z.par_depth) <= threads) ++z.par_depth;
         cpus.enter(threads);
         z.cpus = &cpus;
+        lap("allocate");
         z.build(0, n, 0, 0, 0);
+        lap("build");
         E = 6 * n;
         chunks = threads;
         std::vector<size_t> counts((size_t)chunks, 0);
-        for_chunks([&](int c) { counts[(size_t)c] = faces(chunk_begin(c), chunk_begin(c + 1), nullptr); });
+        staged.resize((size_t)chunks);
+        for_chunks([&](int c) {
+            // a triangle is listed by its lowest half-edge and a face has three: at most one triangle per half-edge of the chunk
+            const int e0 = chunk_begin(c), e1 = chunk_begin(c + 1);
+            staged[(size_t)c].reset(new Triangle[(size_t)(e1 - e0)]);  // Triangle() writes nothing: only the pages that get used are touched
+            counts[(size_t)c] = faces(e0, e1, staged[(size_t)c].get());
+        });
         first.assign((size_t)chunks + 1, 0);
         for (int c = 0; c < chunks; ++c) first[(size_t)c + 1] = first[(size_t)c] + counts[(size_t)c];
+        lap("list faces");
         return true;
     }
     size_t total() const { return first.back(); }
     // all triangles into out[0 .. total())
     void write(Triangle* out) const {
         if (total() == 0) return;
-        for_chunks([&](int c) { faces(chunk_begin(c), chunk_begin(c + 1), out + first[(size_t)c]); });
+        for_chunks([&](int c) {
+            const size_t k = first[(size_t)c + 1] - first[(size_t)c];
+            if (k) std::memcpy(static_cast<void*>(out + first[(size_t)c]), staged[(size_t)c].get(), k * sizeof(Triangle));
+        });
     }
 };
 }  // namespace
@@ -501,10 +532,24 @@ struct Triangulation {
 std::vector<Triangle> Delaunay(const Rect boundRC, const std::vector<Point>& points) {
     (void)boundRC;
     std::vector<Triangle> results;
-    Triangulation t;
-    if (!t.run(points.data(), points.size())) return results;
-    results.resize(t.total());
-    t.write(results.data());
+    const bool timing = std::getenv("MPMVS_HOST_TIMING") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[mpmvs_host]     delaunay: %-18s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t0).count());
+        t0 = now;
+    };
+    {
+        Triangulation t;
+        if (!t.run(points.data(), points.size())) return results;
+        lap("(run)");
+        results.resize(t.total());
+        lap("result storage");
+        t.write(results.data());
+        lap("copy out");
+    }
+    lap("release");
     return results;
 }
 
@@ -606,7 +651,7 @@ void BuildPrior(const Camera& cam, int width, int height, const std::vector<Tria
             const uint32_t lab = label[(size_t)j * width + i];
             if (lab > 0) {
                 const float d = depth_from_plane(cam, planeParams[lab - 1], i, j);
-                if (d <= depth_max && d >= depth_min) mask.at(j, i) = (float)lab;
+                if (d <= depth_max && d >= depth_min) mask.data[(size_t)j * width + i] = (float)lab;  // (not at(): no stamp write from a parallel loop)
             }
         }
 }

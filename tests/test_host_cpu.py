@@ -463,3 +463,19 @@ def test_resize_linear_equals_independent_fixture(hostlib):
         got = hostlib.resize_linear(src, new_cols, new_rows)
         err = np.abs(got.astype(np.float64) - want.astype(np.float64)).max()
         assert err <= 255.0 * 1e-5, f"case {k}: max |difference| {err}"
+
+
+def test_unassigned_cell_points_are_pixel_zero(hostlib):
+    """GetTriangulateVertices, geomPlanarPrior branch (reference src/PatchMatch.cpp:810-850): the cell's threshold is
+    0.85 x cost sum / (r_bound x c_bound); costs of a geometric Run() reach 2.6 and the first cell divides by 25, so the
+    threshold can exceed the initial 2.0 of minCosts -- the reference then pushes its never-assigned `points(3)`, i.e. pixel
+    (0, 0), three times.  The mirror reproduces that (and its Delaunay triangulation drops the duplicates)."""
+    costs = np.full((10, 10), 0.5, np.float32)
+    geom = np.full((10, 10), 3.0, np.float32)          # nothing is geometrically consistent: no pixel qualifies anywhere
+    costs[:5, :5] = 2.6                                # first cell: 0.85 * 65 / 25 = 2.21 > 2.0
+    v = hostlib.triangulate_vertices(costs, geom, True)
+    assert v.tolist() == [[0, 0], [0, 0], [0, 0]]
+    geom[7, 8] = 0.0                                   # one consistent pixel in the last cell: threshold max(0.85 * 12.5 / 100, 0.2) = 0.2 < 0.5
+    assert hostlib.triangulate_vertices(costs, geom, True).tolist() == [[0, 0], [0, 0], [0, 0]]
+    costs[7, 8] = 0.1
+    assert hostlib.triangulate_vertices(costs, geom, True).tolist() == [[0, 0], [0, 0], [0, 0], [8, 7]]
