@@ -28,6 +28,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <memory>
 #include <thread>
 #include <vector>
@@ -143,47 +146,121 @@ void TriangulateVertices(int width, int height, const float* costs, const float*
 namespace {
 typedef __int128 i128;
 
-// Worker threads are placed explicitly: on the target hosts (micro-VM kernels) freshly created threads stay on their
-// creator's CPU for tens of milliseconds -- longer than the whole triangulation -- so a pool that relies on the scheduler's
-// load balancing runs serialised.  Each call takes a different stretch of the allowed CPUs (several Problems triangulate at
-// once in the multi-Problem schedule); the caller's thread is put on the first CPU of the stretch and restored afterwards.
-struct CpuPlacement {
-    std::vector<int> allowed;
-    cpu_set_t original;
-    int base = 0;
-    bool moved = false;
-    CpuPlacement() {
-        CPU_ZERO(&original);
-        if (sched_getaffinity(0, sizeof(original), &original) == 0)
+// Worker threads: a persistent pool, created on first use and pinned once, each worker to its own CPU of the process's
+// affinity mask.  (Until round 3 every call spawned its own threads and pinned them: on the target hosts -- micro-VM kernels --
+// a freshly created thread stays on its creator's CPU for tens of milliseconds, longer than the whole triangulation, and even
+// with explicit placement the 15 thread creations and migrations of a call cost more than the triangulation itself:
+// 22 ms on 16 threads against 60 ms on one.)  One call at a time uses the pool; a caller that finds it busy -- several
+// Problems triangulate at once in the multi-Problem schedule -- runs its triangulation on its own thread instead.
+class HostPool {
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable wake;
+    std::function<void(int)> job;
+    std::atomic<int> next{0}, remaining{0};
+    int ntasks = 0;
+    unsigned long generation = 0;
+    bool quit = false;
+    std::mutex busy;
+
+    void claim_and_run() {
+        for (;;) {
+            const int i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= ntasks) return;
+            job(i);
+            remaining.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    void worker(int slot, std::vector<int> cpus) {
+        if (cpus.size() >= 2) {
+            cpu_set_t one;
+            CPU_ZERO(&one);
+            CPU_SET(cpus[(size_t)slot % cpus.size()], &one);
+            pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+        }
+        unsigned long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                wake.wait(lk, [&] { return quit || generation != seen; });
+                if (quit) return;
+                seen = generation;
+            }
+            claim_and_run();
+        }
+    }
+
+   public:
+    explicit HostPool(int threads) {
+        std::vector<int> cpus;
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0)
             for (int i = 0; i < CPU_SETSIZE; ++i)
-                if (CPU_ISSET(i, &original)) allowed.push_back(i);
+                if (CPU_ISSET(i, &set)) cpus.push_back(i);
+        // slot 0 is the caller's place: the workers take the CPUs after it, spread over the mask (SMT siblings are usually
+        // numbered half the mask apart, so neighbours in the list are distinct cores)
+        for (int t = 1; t < threads; ++t) workers.emplace_back(&HostPool::worker, this, t, cpus);
     }
-    void pin(int slot) const {
-        if (allowed.size() < 2) return;
-        cpu_set_t one;
-        CPU_ZERO(&one);
-        CPU_SET(allowed[(size_t)(base + slot) % allowed.size()], &one);
-        pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+        }
+        wake.notify_all();
+        for (std::thread& t : workers) t.join();
     }
-    void enter(int threads) {
-        static std::atomic<unsigned> calls{0};
-        if (threads < 2 || allowed.size() < 2) return;
-        base = (int)((calls.fetch_add(1) * (unsigned)threads) % allowed.size());
-        pin(0);
-        moved = true;
-    }
-    ~CpuPlacement() {
-        if (moved) pthread_setaffinity_np(pthread_self(), sizeof(original), &original);
+    int size() const { return (int)workers.size() + 1; }
+    bool try_acquire() { return busy.try_lock(); }
+    void release() { busy.unlock(); }
+    // fn(i) for i in [0, n) on the workers and the caller; returns when all are done.  Only between try_acquire / release.
+    void run(int n, const std::function<void(int)>& fn) {
+        if (n <= 0) return;
+        if (n == 1 || workers.empty()) {
+            for (int i = 0; i < n; ++i) fn(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = fn;
+            ntasks = n;
+            next.store(0, std::memory_order_relaxed);
+            remaining.store(n, std::memory_order_relaxed);
+            ++generation;
+        }
+        wake.notify_all();
+        claim_and_run();
+        while (remaining.load(std::memory_order_acquire) > 0) std::this_thread::yield();
     }
 };
 
+int HostThreads() {
+    if (const char* e = std::getenv("MPMVS_HOST_THREADS")) return std::max(1, std::atoi(e));
+    const unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::min(16u, std::max(1u, hc));
+}
+// The pool of the process, acquired for one triangulation: nullptr when one thread is asked for or when another caller holds
+// it.  It is rebuilt when MPMVS_HOST_THREADS asks for another size than it has (tests walk through thread counts).
+HostPool* AcquireSharedPool() {
+    static std::mutex mu;
+    static std::unique_ptr<HostPool> pool;
+    std::lock_guard<std::mutex> lk(mu);
+    const int want = HostThreads();
+    if (want < 2) return nullptr;
+    if (pool && pool->size() == want) return pool->try_acquire() ? pool.get() : nullptr;
+    if (pool) {
+        if (!pool->try_acquire()) return nullptr;  // in use at its old size: this caller runs on its own thread
+        pool->release();
+    }
+    pool.reset(new HostPool(want));
+    return pool->try_acquire() ? pool.get() : nullptr;
+}
+
 struct Zipper {
-    const CpuPlacement* cpus = nullptr;
     const Point* P;
     bool wide;  // coordinates span 2^13 or more: the in-circle determinant needs 128 bits
     // not value-initialised: every piece sets up its own slots, so the pages are first touched by the thread that uses them
     std::unique_ptr<int[]> next, prev, org, ids;
-    int par_depth = 0;
 
     struct Piece {
         int le, re;              // ccw hull edge out of the first point / cw hull edge out of the last point (in the piece's order)
@@ -308,25 +385,21 @@ struct Zipper {
         return pc;
     }
 
-    // `slot` numbers the thread that runs this subtree (0 = the caller's): a new thread takes the left half
-    Piece build(int l, int r, int axis, int depth, int slot) {
+    // the piece of the points ids[l .. r), cut along `axis`, on the calling thread
+    Piece build(int l, int r, int axis) {
         const int n = r - l;
         if (n <= 3) return leaf(l, r, axis);
         const int m = l + n / 2;
+        split(l, m, r, axis);
+        Piece L = build(l, m, axis ^ 1);
+        Piece R = build(m, r, axis ^ 1);
+        return merge(L, R, axis);
+    }
+    void split(int l, int m, int r, int axis) {
         std::nth_element(ids.get() + l, ids.get() + m, ids.get() + r, [&](int a, int b) { return before(axis, a, b); });
-        Piece L, R;
-        if (depth < par_depth) {
-            const int left_slot = slot + (1 << (par_depth - depth - 1));
-            std::thread left([&] {
-                cpus->pin(left_slot);
-                L = build(l, m, axis ^ 1, depth + 1, left_slot);
-            });
-            R = build(m, r, axis ^ 1, depth + 1, slot);
-            left.join();
-        } else {
-            L = build(l, m, axis ^ 1, depth + 1, slot);
-            R = build(m, r, axis ^ 1, depth + 1, slot);
-        }
+    }
+    // zips the triangulated halves of a cut along `axis` together
+    Piece merge(Piece L, Piece R, int axis) {
         reorient(L, axis);
         reorient(R, axis);
         Piece pc;
@@ -385,11 +458,6 @@ struct Zipper {
     }
 };
 
-int HostThreads() {
-    if (const char* e = std::getenv("MPMVS_HOST_THREADS")) return std::max(1, std::atoi(e));
-    const unsigned hc = std::thread::hardware_concurrency();
-    return (int)std::min(16u, std::max(1u, hc));
-}
 }  // namespace
 
 namespace {
@@ -434,11 +502,19 @@ bool DistinctPoints(const Point* pts, size_t count, std::vector<Point>& out, boo
 struct Triangulation {
     std::vector<Point> pts;
     Zipper z;
-    CpuPlacement cpus;
-    int threads = 1, chunks = 1, E = 0;
+    HostPool* pool = nullptr;  // held for the duration of run() + write() when not null
+    int chunks = 1, E = 0;
     std::vector<size_t> first;  // first[c] = number of triangles in the half-edge chunks before c; first[chunks] = total
+    // Every chunk of half-edges lists its triangles ONCE into a staging buffer of its own (first touched by the thread that
+    // fills it); write() then only copies.  (Until round 3 the faces were walked twice, once to count and once to write:
+    // two pointer-chasing passes over 6 n half-edges.)
+    std::vector<std::unique_ptr<Triangle[]>> staged;
 
-    // the triangles whose lowest half-edge lies in [e0, e1): counted (out == nullptr) or written
+    ~Triangulation() {
+        if (pool) pool->release();
+    }
+
+    // the triangles whose lowest half-edge lies in [e0, e1), written to out; returns their number
     size_t faces(int e0, int e1, Triangle* out) const {
         size_t k = 0;
         for (int e = e0; e < e1; ++e) {
@@ -450,28 +526,45 @@ struct Triangulation {
             if (e3 < e || z.dest(e3) != a) continue;
             const int b = z.org[e2], c = z.org[e3];
             if (z.ccw(a, b, c) <= 0) continue;  // the outer face of a three-cornered hull
-            if (out) out[k] = Triangle(pts[(size_t)a], pts[(size_t)b], pts[(size_t)c]);
-            ++k;
+            out[k++] = Triangle(pts[(size_t)a], pts[(size_t)b], pts[(size_t)c]);
         }
         return k;
     }
-    template <class F>
-    void for_chunks(F&& fn) const {
-        std::vector<std::thread> pool;
-        for (int c = 1; c < chunks; ++c)
-            pool.emplace_back([&, c] {
-                cpus.pin(c);
-                fn(c);
-            });
-        fn(0);
-        for (std::thread& t : pool) t.join();
+    void parallel(int n, const std::function<void(int)>& fn) const {
+        if (pool)
+            pool->run(n, fn);
+        else
+            for (int i = 0; i < n; ++i) fn(i);
     }
     int chunk_begin(int c) const { return (int)((long long)E * c / chunks); }
 
-    // Every chunk of half-edges lists its triangles ONCE into a staging buffer of its own (first touched by the thread that
-    // fills it); write() then only copies.  (Until round 3 the faces were walked twice, once to count and once to write:
-    // two pointer-chasing passes over 6 n half-edges.)
-    std::vector<std::unique_ptr<Triangle[]>> staged;
+    // Divide and conquer, level by level, so that every level is one parallel sweep of the pool: the cuts of the top `depth`
+    // levels (level d: 2^d medians, each over its own range), then the 2^depth subtrees (each built on one thread), then the
+    // merges back up.  The ranges, the order of the points inside them and therefore the triangulation are the ones the plain
+    // recursion produces: the result does not depend on the number of threads.
+    void build_levels(int n, int depth) {
+        std::vector<std::vector<int>> bound((size_t)depth + 1);  // bound[d]: the 2^d + 1 range boundaries of level d
+        bound[0] = {0, n};
+        for (int d = 0; d < depth; ++d) {
+            const std::vector<int>& b = bound[(size_t)d];
+            std::vector<int>& nb = bound[(size_t)d + 1];
+            nb.resize(2 * (b.size() - 1) + 1);
+            for (size_t i = 0; i + 1 < b.size(); ++i) {
+                nb[2 * i] = b[i];
+                nb[2 * i + 1] = b[i] + (b[i + 1] - b[i]) / 2;
+            }
+            nb.back() = n;
+            parallel((int)b.size() - 1, [&](int i) { z.split(b[(size_t)i], nb[2 * (size_t)i + 1], b[(size_t)i + 1], d & 1); });
+        }
+        std::vector<Zipper::Piece> piece((size_t)1 << depth);
+        const std::vector<int>& lb = bound[(size_t)depth];
+        parallel((int)piece.size(), [&](int i) { piece[(size_t)i] = z.build(lb[(size_t)i], lb[(size_t)i + 1], depth & 1); });
+        for (int d = depth - 1; d >= 0; --d) {
+            std::vector<Zipper::Piece> up((size_t)1 << d);
+            parallel((int)up.size(), [&](int i) { up[(size_t)i] = z.merge(piece[2 * (size_t)i], piece[2 * (size_t)i + 1], d & 1); });
+            piece.swap(up);
+        }
+    }
 
     bool run(const Point* points, size_t count) {
         bool wide = false;
@@ -495,18 +588,21 @@ struct Triangulation {
         z.org.reset(new int[(size_t)6 * n]);
         z.ids.reset(new int[(size_t)n]);
         for (int i = 0; i < n; ++i) z.ids[i] = i;
-        threads = n >= 4096 ? HostThreads() : 1;
-        while ((2 << z.par_depth) <= threads) ++z.par_depth;
-        cpus.enter(threads);
-        z.cpus = &cpus;
+        if (n >= 4096) {
+            pool = AcquireSharedPool();  // nullptr: one thread asked for, or another Problem's triangulation has the pool -- run on this thread
+        }
+        const int threads = pool ? pool->size() : 1;
         lap("allocate");
-        z.build(0, n, 0, 0, 0);
+        // four subtrees per thread: the pool's dynamic claiming evens out what the point distribution makes uneven
+        int depth = 0;
+        while (pool && (1 << depth) < 4 * threads && (n >> (depth + 1)) >= 512) ++depth;
+        build_levels(n, depth);
         lap("build");
         E = 6 * n;
-        chunks = threads;
+        chunks = pool ? 4 * threads : 1;
         std::vector<size_t> counts((size_t)chunks, 0);
         staged.resize((size_t)chunks);
-        for_chunks([&](int c) {
+        parallel(chunks, [&](int c) {
             // a triangle is listed by its lowest half-edge and a face has three: at most one triangle per half-edge of the chunk
             const int e0 = chunk_begin(c), e1 = chunk_begin(c + 1);
             staged[(size_t)c].reset(new Triangle[(size_t)(e1 - e0)]);  // Triangle() writes nothing: only the pages that get used are touched
@@ -521,7 +617,7 @@ struct Triangulation {
     // all triangles into out[0 .. total())
     void write(Triangle* out) const {
         if (total() == 0) return;
-        for_chunks([&](int c) {
+        parallel(chunks, [&](int c) {
             const size_t k = first[(size_t)c + 1] - first[(size_t)c];
             if (k) std::memcpy(static_cast<void*>(out + first[(size_t)c]), staged[(size_t)c].get(), k * sizeof(Triangle));
         });
