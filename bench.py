@@ -23,15 +23,14 @@ collective (weak scaling); RCCL only provides the barrier and the max-reduce of 
 sharded over the ranks, the shipped schedule (photometric 3 scales -> geometric + planar prior -> geometric), ONE
 all_gather_into_tensor of the depth maps per pass over RCCL (mp-mvs_amd/schedule.py); strong scaling.
 """
-import os
-# the CPU baseline's OpenMP runtime reads these when it starts: threads stay on the core they start on, one place per core
-os.environ.setdefault("OMP_PROC_BIND", "close")
-os.environ.setdefault("OMP_PLACES", "cores")
 import argparse
 import ctypes
 import importlib
 import json
+import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -213,12 +212,9 @@ def host_cpu_facts():
     return len(cpus), len(cores), quota
 
 
-def cpu_baseline(pm, ctx, cams, imgs, prm, seed):
-    """the oracle (our CPU port; the reference has no CPU path, SURVEY F2) on the host cores.  Three thread counts -- 16 (the
-    share of one GPU on the pool's boxes), the physical cores and all hardware threads, OMP_PROC_BIND=close -- are timed on a
-    bounded sample (the same Problem rendered at half the size in each direction: same views, schedule and seed; Mpix/s does
-    not depend on the image size); the best of them then runs the WHOLE workload, which gives `value` and, since both results
-    are at hand, a bit-for-bit comparison with the HIP path's."""
+def cpu_baseline_child(out_path, seed, quantize=True):
+    """runs in a child process of its own (see cpu_baseline): the oracle on the host cores, nothing else loaded"""
+    pm = importlib.import_module("mp-mvs_amd")
     from oracle import binding as ob
     avail, physical, quota = host_cpu_facts()
     counts = sorted({min(16, avail), physical, avail})
@@ -236,6 +232,9 @@ def cpu_baseline(pm, ctx, cams, imgs, prm, seed):
         o.run(prm_s, seed)
         sample[n] = ws * hs / (time.perf_counter() - t0) / 1e6
     best = max(sample, key=sample.get)
+    cams, imgs, _ = load_scene(pm, W, H, V, quantize)
+    dmin, dmax = pm.synth.kernel_depth_range(cams[0])
+    prm = pm.PatchMatchParams(num_images=V + 1, depth_min=float(dmin), depth_max=float(dmax), max_scale=0, max_iterations=ITERS)
     ob.set_num_threads(best)
     o = ob.create()
     o.set_views(cams, imgs)
@@ -243,14 +242,38 @@ def cpu_baseline(pm, ctx, cams, imgs, prm, seed):
     o.run(prm, seed)
     dt = time.perf_counter() - t0
     op, oc = o.get()
+    np.savez(out_path, planes=op, costs=oc)
+    print(json.dumps({"best": best, "dt": dt, "sample": {str(k): v for k, v in sample.items()}, "avail": avail, "physical": physical, "quota": quota,
+                      "bind": os.environ.get("OMP_PROC_BIND"), "places": os.environ.get("OMP_PLACES")}), flush=True)
+
+
+def cpu_baseline(pm, ctx, cams, imgs, prm, seed, quantize=True):
+    """the oracle (our CPU port; the reference has no CPU path, SURVEY F2) on the host cores.  Three thread counts -- 16 (the
+    share of one GPU on the pool's boxes), the physical cores and all hardware threads, OMP_PROC_BIND=close -- are timed on a
+    bounded sample (the same Problem rendered at half the size in each direction: same views, schedule and seed; Mpix/s does
+    not depend on the image size); the best of them then runs the WHOLE workload, which gives `value` and, since both results
+    are at hand, a bit-for-bit comparison with the HIP path's.  It runs in a child process: the OpenMP binding variables make
+    the runtime pin the process's first thread to one core, and every thread created afterwards would inherit that mask."""
+    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores")
+    with tempfile.TemporaryDirectory() as tmp:
+        out_path = os.path.join(tmp, "oracle_result.npz")
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", out_path, "--child-seed", str(seed)] +
+                           ([] if quantize else ["--float-images"]), env=env,
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            return {"value": None, "unit": "Mpix/s", "cores": 0, "kind": "port", "sample": "the CPU baseline child failed: " + r.stderr[-400:]}
+        info = json.loads(r.stdout.strip().splitlines()[-1])
+        z = np.load(out_path)
+        op, oc = z["planes"], z["costs"]
     ctx.run(prm, seed)             # untimed
     gp, gc = ctx.get()
+    best, dt, sample, quota = info["best"], info["dt"], info["sample"], info["quota"]
     return {"value": round(W * H / dt / 1e6, 5), "unit": "Mpix/s", "cores": best, "kind": "port",
-            "sample": f"thread count chosen on a bounded sample (the same Problem at {ws}x{hs}: {', '.join(f'{n} threads {v:.4f} Mpix/s' for n, v in sample.items())}); "
+            "sample": f"thread count chosen on a bounded sample (the same Problem at {W // 2}x{H // 2}: {', '.join(f'{n} threads {v:.4f} Mpix/s' for n, v in sample.items())}); "
                       f"`value` = the whole workload (one {W}x{H} Problem, {V} src views, same inputs, seed and Run() schedule) on {best} threads, {dt:.1f} s; "
-                      f"OpenMP oracle, OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}; host: {avail} hardware threads / {physical} physical cores usable, "
-                      f"container CPU quota {'none' if quota is None else f'{quota:g} CPUs'}",
-            "threads_tried_Mpix_per_s": {str(n): round(v, 5) for n, v in sample.items()},
+                      f"OpenMP oracle in a child process, OMP_PROC_BIND={info['bind']} OMP_PLACES={info['places']}; host: {info['avail']} hardware threads / "
+                      f"{info['physical']} physical cores usable, container CPU quota {'none' if quota is None else f'{quota:g} CPUs'}",
+            "threads_tried_Mpix_per_s": {k: round(v, 5) for k, v in sample.items()},
             "hip_result_bit_identical": bool(np.array_equal(op, gp) and np.array_equal(oc, gc))}
 
 
@@ -436,7 +459,12 @@ def main():
     ap.add_argument("--cfg4-size", default="1600x1200")
     ap.add_argument("--cfg4-grid", type=int, default=8)
     ap.add_argument("--workers", type=int, default=6, help="cfg4: host threads per rank driving its Problems (measured on one MI355X, 64 Problems: 1 / 3 / 6 / 10 threads 14.6 / 10.7 / 9.4 / 9.7 s)")
+    ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--child-seed", type=int, default=12345, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_child:
+        cpu_baseline_child(args.cpu_baseline_child, args.child_seed, not args.float_images)
+        return
     if args.steps is None:
         args.steps = 5 if args.workload == "cfg1" else 1
     if args.warmup is None:
@@ -581,7 +609,7 @@ def main():
             ctx = engine.create(dev_index)
             ctx.set_views(cams, imgs)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pm, ctx, cams, imgs, prm, seed)
+            out["cpu_baseline"] = cpu_baseline(pm, ctx, cams, imgs, prm, seed, quantize)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -18,6 +18,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <condition_variable>
 #include <string>
 #include <atomic>
 #include <thread>
@@ -297,101 +299,153 @@ static int upload_problem(mpmvs_ctx* c) {
     return 0;
 }
 
-// host image -> dense staging buffer -> replicate-padded resident image
-static int upload_padded(mpmvs_ctx* c, const float* host, size_t pitch, int w, int h, int apron, float** out) {
-    float* d_raw = nullptr;
-    HIPCHK(c, pool_malloc(&d_raw, (size_t)w * h * 4));
-    const int pw = w + 2 * apron, ph = h + 2 * apron;
-    float* d_pad = nullptr;
-    int rc = 0;
-    if (pool_malloc(&d_pad, (size_t)pw * ph * 4) != hipSuccess) rc = -100;
-    if (!rc && hipMemcpy2DAsync(d_raw, (size_t)w * 4, host, pitch, (size_t)w * 4, h, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = -100;
-    if (!rc) {
-        hipLaunchKernelGGL(k_pad, dim3((pw + 255) / 256, ph), dim3(256), 0, c->stream, d_raw, w, h, d_pad, apron);
-        if (hipGetLastError() != hipSuccess) rc = -100;
+// ---------------------------------------------------------------------------
+// Image upload (CudaMemInit's image half, ref .cpp:999-1025).  The caller's images are pageable fp32 arrays; copied as they
+// are, the runtime stages them through its own bounce buffers at a fraction of the PCIe rate and every copy is synchronous.
+// Here the rows are converted (8-bit exact images: to bytes, which also quarters the traffic) or copied into ONE page-locked
+// staging buffer by a few host threads, go to the device in asynchronous DMA transfers, and are unpacked there; the call
+// synchronises once, at its end.
+// ---------------------------------------------------------------------------
+namespace {
+// a small persistent pool for the row work (thread creation costs as much as converting an image); a caller that finds it
+// busy -- several Problems upload at once in the multi-Problem schedule -- works with a few short-lived threads instead
+class RowPool {
+    std::vector<std::thread> workers;
+    std::mutex mu, busy;
+    std::condition_variable wake;
+    const std::function<void()>* job = nullptr;
+    std::atomic<int> running{0};
+    unsigned long generation = 0;
+    bool quit = false;
+    void worker() {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void()>* fn;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                wake.wait(lk, [&] { return quit || generation != seen; });
+                if (quit) return;
+                seen = generation;
+                fn = job;
+            }
+            (*fn)();
+            running.fetch_sub(1, std::memory_order_release);
+        }
     }
-    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = -100;  // also on failure: nothing may still use what goes back to the pool
-    (void)pool_free(d_raw);
-    if (rc) {
-        (void)pool_free(d_pad);
-        c->err = "upload of the reference image failed";
-        return rc;
+
+   public:
+    RowPool() {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int n = (int)std::max(1u, std::min(16u, hw ? hw : 1u));
+        for (int t = 1; t < n; ++t) workers.emplace_back(&RowPool::worker, this);
     }
-    *out = d_pad;
-    return 0;
+    ~RowPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+        }
+        wake.notify_all();
+        for (std::thread& t : workers) t.join();
+    }
+    // fn() on every worker and on the caller (fn pulls its own work items from a shared counter)
+    void run(const std::function<void()>& fn) {
+        if (!busy.try_lock()) {
+            std::vector<std::thread> tmp;
+            for (int t = 0; t < 3; ++t) tmp.emplace_back(fn);
+            fn();
+            for (std::thread& t : tmp) t.join();
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = &fn;
+            running.store((int)workers.size(), std::memory_order_relaxed);
+            ++generation;
+        }
+        wake.notify_all();
+        fn();
+        while (running.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+        busy.unlock();
+    }
+};
+RowPool& row_pool() {
+    static RowPool p;
+    return p;
 }
 
-// host image -> dense staging buffer -> quad-packed fp32 texture (w x h float4) at d_e
-static int upload_extended(mpmvs_ctx* c, const float* host, size_t pitch, int w, int h, float* d_e) {
-    float* d_raw = nullptr;
-    HIPCHK(c, pool_malloc(&d_raw, (size_t)w * h * 4));
-    int rc = 0;
-    if (hipMemcpy2DAsync(d_raw, (size_t)w * 4, host, pitch, (size_t)w * 4, h, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = -100;
-    if (!rc) {
-        hipLaunchKernelGGL(k_pack_quads_f32, dim3((w + 255) / 256, h), dim3(256), 0, c->stream, d_raw, w, h, (float4*)d_e);
-        if (hipGetLastError() != hipSuccess) rc = -100;
+struct PinnedBuf {
+    void* p = nullptr;
+    ~PinnedBuf() {
+        if (p) mpmvs_free_pinned(p);
     }
-    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = -100;  // also on failure: the staging buffer goes back to the pool
-    (void)pool_free(d_raw);
-    if (rc) c->err = "upload of a source image failed";
-    return rc;
-}
+};
+}  // namespace
 
-// 8-bit host image -> (shared staging buffer) -> quad-packed u8 texture at d_q.  Stream ordered: the staging buffer may be
-// overwritten by the next view's copy once this pack kernel has been enqueued.
-static int upload_quads_u8(mpmvs_ctx* c, const unsigned char* host8, unsigned char* d_stage, int w, int h, uint32_t* d_q) {
-    HIPCHK(c, hipMemcpyAsync(d_stage, host8, (size_t)w * h, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_pack_quads_u8, dim3((w + 255) / 256, h), dim3(256), 0, c->stream, d_stage, w, h, (uint2*)d_q);
-    HIPCHK(c, hipGetLastError());
-    return 0;
-}
-
-// Are all source images integers in [0, 255] (the reference's imread(GRAYSCALE) -> CV_32F path)?  Checked and converted to
-// 8 bit in one pass, rows dealt to a few host threads; out8[v-1] receives view v's bytes.  Returns false at the first
-// non-integer pixel (the fp32 texture format is used then).
-static bool convert_sources_u8(int n, const mpmvs_camera* cams, const float* const* images, const size_t* pitch_bytes,
-                               std::vector<std::vector<unsigned char>>& out8) {
-    out8.assign(n - 1, std::vector<unsigned char>());
-    long total_rows = 0;
-    for (int v = 1; v < n; ++v) {
-        out8[v - 1].resize((size_t)cams[v].width * cams[v].height);
-        total_rows += cams[v].height;
+// Stages the n images: slot[i] = byte offset of image i in `stage` (room for w * h floats each).  An image whose pixels are all
+// integers in [0, 255] (the reference's imread(GRAYSCALE) -> CV_32F input, ref .cpp:877-882) is staged as w * h BYTES and
+// is_u8[i] set; the sources are treated as one group (the texture format is the same for all of them: `src_u8`), view 0 on
+// its own.  Rows are dealt to the pool in chunks; a group found inexact is staged again as fp32 rows.
+static void stage_images(int n, const mpmvs_camera* cams, const float* const* images, const size_t* pitch_bytes, bool try_src_u8, char* stage,
+                         const std::vector<size_t>& slot, bool& ref_u8, bool& src_u8) {
+    std::vector<long> row0(n + 1, 0);
+    for (int i = 0; i < n; ++i) row0[i + 1] = row0[i] + cams[i].height;
+    const long total_rows = row0[n];
+    auto image_of_row = [&](long k) {
+        int i = 0;
+        while (k >= row0[i + 1]) ++i;
+        return i;
+    };
+    std::atomic<bool> ref_exact(true), src_exact(try_src_u8);
+    {
+        std::atomic<long> next(0);
+        const std::function<void()> work = [&]() {
+            const long chunk = 32;
+            for (;;) {
+                const long r0 = next.fetch_add(chunk);
+                if (r0 >= total_rows) return;
+                int i = image_of_row(r0);
+                for (long k = r0; k < std::min(r0 + chunk, total_rows); ++k) {
+                    while (k >= row0[i + 1]) ++i;
+                    std::atomic<bool>& exact = i == 0 ? ref_exact : src_exact;
+                    if (!exact.load(std::memory_order_relaxed)) continue;
+                    const int y = (int)(k - row0[i]), w = cams[i].width;
+                    const size_t pitch = pitch_bytes ? pitch_bytes[i] : (size_t)w * 4;
+                    const float* row = (const float*)((const char*)images[i] + (size_t)y * pitch);
+                    unsigned char* o = (unsigned char*)(stage + slot[i]) + (size_t)y * w;
+                    bool ok = true;
+                    for (int x = 0; x < w; ++x) {
+                        const float f = row[x];
+                        const int q = (int)(f >= 0.0f && f <= 255.0f ? f : -1.0f);
+                        ok &= (float)q == f;
+                        o[x] = (unsigned char)q;
+                    }
+                    if (!ok) exact.store(false, std::memory_order_relaxed);
+                }
+            }
+        };
+        row_pool().run(work);
     }
-    std::atomic<bool> exact(true);
+    ref_u8 = ref_exact.load();
+    src_u8 = src_exact.load();
+    if (ref_u8 && src_u8) return;
+    // second sweep: the fp32 rows of whatever is not 8-bit exact
     std::atomic<long> next(0);
-    auto work = [&]() {
-        const long chunk = 64;
+    const std::function<void()> work = [&]() {
+        const long chunk = 32;
         for (;;) {
             const long r0 = next.fetch_add(chunk);
-            if (r0 >= total_rows || !exact.load(std::memory_order_relaxed)) return;
-            long v = 1, base = 0;
+            if (r0 >= total_rows) return;
+            int i = image_of_row(r0);
             for (long k = r0; k < std::min(r0 + chunk, total_rows); ++k) {
-                while (k - base >= cams[v].height) base += cams[v++].height;
-                const int y = (int)(k - base), w = cams[v].width;
-                const size_t pitch = pitch_bytes ? pitch_bytes[v] : (size_t)w * 4;
-                const float* row = (const float*)((const char*)images[v] + (size_t)y * pitch);
-                unsigned char* o = out8[v - 1].data() + (size_t)y * w;
-                bool ok = true;
-                for (int x = 0; x < w; ++x) {
-                    const float f = row[x];
-                    const int q = (int)(f >= 0.0f && f <= 255.0f ? f : -1.0f);
-                    ok &= (float)q == f;
-                    o[x] = (unsigned char)q;
-                }
-                if (!ok) {
-                    exact.store(false, std::memory_order_relaxed);
-                    return;
-                }
+                while (k >= row0[i + 1]) ++i;
+                if (i == 0 ? ref_u8 : src_u8) continue;
+                const int y = (int)(k - row0[i]), w = cams[i].width;
+                const size_t pitch = pitch_bytes ? pitch_bytes[i] : (size_t)w * 4;
+                std::memcpy(stage + slot[i] + (size_t)y * w * 4, (const char*)images[i] + (size_t)y * pitch, (size_t)w * 4);
             }
         }
     };
-    const unsigned hw = std::thread::hardware_concurrency();
-    const int nthreads = (int)std::max(1u, std::min(8u, hw ? hw : 1u));
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nthreads; ++t) pool.emplace_back(work);
-    work();
-    for (std::thread& t : pool) t.join();
-    return exact.load();
+    row_pool().run(work);
 }
 
 extern "C" {
@@ -453,55 +507,69 @@ static int set_views_impl(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const f
     c->H = cams[0].height;
     std::memset(&c->hP, 0, sizeof(ProblemDev));
     precompute_views(c);
-    int rc;
-    {
-        const size_t pitch = pitch_bytes ? pitch_bytes[0] : (size_t)c->W * 4;
-        if ((rc = upload_padded(c, images[0], pitch, c->W, c->H, kRefApron, &c->d_ref))) return rc;
-        c->hP.ref_pitch = c->W + 2 * kRefApron;
-        c->hP.ref_img = c->d_ref + (size_t)kRefApron * c->hP.ref_pitch + kRefApron;
+    // host staging (page-locked, pooled) and its device twin: a slot of w * h floats per image, 256-byte aligned
+    std::vector<size_t> slot(n + 1, 0);
+    for (int i = 0; i < n; ++i) slot[i + 1] = slot[i] + (((size_t)cams[i].width * cams[i].height * 4 + 255) & ~(size_t)255);
+    PinnedBuf stage;
+    stage.p = mpmvs_alloc_pinned(slot[n]);
+    if (!stage.p) return fail(c, -100, "no page-locked staging memory for the images");
+    bool ref_u8 = false, src_u8 = false;
+    // 8-bit exact sources (the reference's imread path, ref .cpp:877-882) take the 8-byte fp16 texel format; anything else,
+    // or force_f32, the 16-byte fp32 one
+    stage_images(n, cams, images, pitch_bytes, !c->force_f32, (char*)stage.p, slot, ref_u8, src_u8);
+    c->all_u8 = src_u8;
+    PoolBuf d_stage;  // back to the pool when the call returns; every return path synchronises the stream first
+    HIPCHK(c, d_stage.alloc(slot[n]));
+    int rc = 0;
+    auto failed = [&](const char* what) {
+        (void)hipStreamSynchronize(c->stream);
+        c->err = what;
+        return -100;
+    };
+    for (int i = 0; i < n && !rc; ++i) {
+        const size_t bytes = (size_t)cams[i].width * cams[i].height * ((i == 0 ? ref_u8 : src_u8) ? 1 : 4);
+        if (hipMemcpyAsync(d_stage.as<char>() + slot[i], (const char*)stage.p + slot[i], bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = -100;
     }
-    // 8-bit exact input (the reference's imread path, ref .cpp:877-882) takes the
-    // quad-packed u8 texture format; anything else stays fp32
-    std::vector<std::vector<unsigned char>> src8;
-    bool exact = !c->force_f32 && convert_sources_u8(n, cams, images, pitch_bytes, src8);
-    c->all_u8 = exact;
+    if (rc) return failed("upload of the images failed");
+    // reference image: replicate-padded fp32
+    {
+        const int pw = c->W + 2 * kRefApron, ph = c->H + 2 * kRefApron;
+        if (pool_malloc(&c->d_ref, (size_t)pw * ph * 4) != hipSuccess) return failed("allocation of the reference image failed");
+        if (ref_u8)
+            hipLaunchKernelGGL(k_pad_u8, dim3((pw + 255) / 256, ph), dim3(256), 0, c->stream, d_stage.as<unsigned char>() + slot[0], c->W, c->H, c->d_ref, kRefApron);
+        else
+            hipLaunchKernelGGL(k_pad, dim3((pw + 255) / 256, ph), dim3(256), 0, c->stream, (const float*)(d_stage.as<char>() + slot[0]), c->W, c->H, c->d_ref, kRefApron);
+        c->hP.ref_pitch = pw;
+        c->hP.ref_img = c->d_ref + (size_t)kRefApron * pw + kRefApron;
+    }
     // one allocation for the textures of all views, each 256-byte aligned.  Every view is addressed through its own buffer
     // resource (base = the view's first texel, 32-bit offsets inside it), so only a single view is limited to 4 GB
     // (checked by the caller), not the allocation: 32 views of 3200 x 3200 fp32 texels are 5.2 GB.
-    const size_t texel = exact ? 8 : 16;
+    const size_t texel = src_u8 ? 8 : 16;
     std::vector<size_t> tex_off(n, 0);
     size_t tex_total = 0;
     for (int v = 1; v < n; ++v) {
         tex_off[v] = tex_total;
         tex_total += ((size_t)cams[v].width * cams[v].height * texel + 255) & ~(size_t)255;
     }
-    HIPCHK(c, pool_malloc(&c->d_tex_all, tex_total));
-    if (exact) c->d_src8.assign(n - 1, nullptr); else c->d_src.assign(n - 1, nullptr);
-    PoolBuf d_stage;  // back to the pool on every return path; the callers synchronise the stream first
-    if (exact) {
-        size_t biggest = 0;
-        for (int v = 1; v < n; ++v) biggest = std::max(biggest, (size_t)cams[v].width * cams[v].height);
-        HIPCHK(c, d_stage.alloc(biggest));
-    }
+    if (pool_malloc(&c->d_tex_all, tex_total) != hipSuccess) return failed("allocation of the source textures failed");
+    if (src_u8) c->d_src8.assign(n - 1, nullptr); else c->d_src.assign(n - 1, nullptr);
     for (int v = 1; v < n; ++v) {
         const int w = cams[v].width, h = cams[v].height;
-        const size_t pitch = pitch_bytes ? pitch_bytes[v] : (size_t)w * 4;
         ViewDev& o = c->hP.views[v - 1];
-        if (exact) {
+        if (src_u8) {
             c->d_src8[v - 1] = (uint32_t*)((char*)c->d_tex_all + tex_off[v]);
-            if ((rc = upload_quads_u8(c, src8[v - 1].data(), d_stage.as<unsigned char>(), w, h, c->d_src8[v - 1]))) {
-                (void)hipStreamSynchronize(c->stream);
-                return rc;
-            }
+            hipLaunchKernelGGL(k_pack_quads_u8, dim3((w + 255) / 256, h), dim3(256), 0, c->stream, d_stage.as<unsigned char>() + slot[v], w, h, (uint2*)c->d_src8[v - 1]);
             o.pitch8 = w;
             o.img8 = c->d_src8[v - 1];
         } else {
             c->d_src[v - 1] = (float*)((char*)c->d_tex_all + tex_off[v]);
-            if ((rc = upload_extended(c, images[v], pitch, w, h, c->d_src[v - 1]))) return rc;
+            hipLaunchKernelGGL(k_pack_quads_f32, dim3((w + 255) / 256, h), dim3(256), 0, c->stream, (const float*)(d_stage.as<char>() + slot[v]), w, h, (float4*)c->d_src[v - 1]);
             o.pitch = w;
             o.img = c->d_src[v - 1];
         }
     }
+    if (hipGetLastError() != hipSuccess) return failed("unpacking the images on the device failed");
     const size_t wh = (size_t)c->W * c->H;
     rc = -100;
     if (pool_malloc(&c->S.planes, wh * 16) == hipSuccess && pool_malloc(&c->S.costs, wh * 4) == hipSuccess &&
@@ -510,7 +578,7 @@ static int set_views_impl(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const f
         hipMemsetAsync(c->S.sel, 0, wh * 4, c->stream) == hipSuccess && hipMemsetAsync(c->S.geom, 0, wh * 4, c->stream) == hipSuccess)
         rc = 0;
     if (rc) c->err = "allocation of the per-pixel state failed";
-    const int rc_up = upload_problem(c);  // synchronises the stream (also on the failure path): the staged 8-bit copies are complete
+    const int rc_up = upload_problem(c);  // synchronises the stream (also on the failure path): both staging buffers are free again
     return rc ? rc : rc_up;
 }
 

@@ -853,6 +853,17 @@ __global__ void k_pad(const float* __restrict__ src, int w, int h, float* __rest
     dst[(long)y * pw + x] = src[(long)sy * w + sx];
 }
 
+// the same from an 8-bit image (an 8-bit exact reference image travels as bytes)
+__global__ void k_pad_u8(const unsigned char* __restrict__ src, int w, int h, float* __restrict__ dst, int apron) {
+    const int pw = w + 2 * apron, ph = h + 2 * apron;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= pw || y >= ph) return;
+    int sx = x - apron, sy = y - apron;
+    sx = sx < 0 ? 0 : (sx > w - 1 ? w - 1 : sx);
+    sy = sy < 0 ? 0 : (sy > h - 1 ? h - 1 : sy);
+    dst[(long)y * pw + x] = (float)src[(long)sy * w + sx];
+}
+
 // dense 8-bit w x h image -> fp16 quad-difference texture (SrcTex8), w x h texels of 8 bytes; the host converts the fp32 input
 // to 8 bit while it checks that every pixel is an integer in [0, 255] (4x less PCIe traffic than staging fp32)
 __global__ void k_pack_quads_u8(const unsigned char* __restrict__ src, int w, int h, uint2* __restrict__ dst) {
