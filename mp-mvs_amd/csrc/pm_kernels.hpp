@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
 
     float4 plane_now = make_float4(0.f, 0.f, 0.f, 0.f), pp = make_float4(0.f, 0.f, 0.f, 0.f);
     float depth_now = 0.0f, cost_now = 0.0f, geom_now = 0.0f, restricted_cost = 0.0f, weight_norm = 0.0f;
-    float depth_prior = 0.0f, cand_depth = 0.0f;
+    float depth_prior = 0.0f;
     // The ingredients of the five refinement candidates are drawn together (the order of the random draws is the
     // reference's) but consumed one evaluation at a time: they wait in private memory, not in registers that the
     // evaluations in between would have to spill.  Normals: 0 = current plane, 1 = random, 2 = perturbed; depths:
@@ -587,7 +587,13 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
     // candidates at consecutive slots (ballot + mbcnt), lane j evaluates item j of the round for whoever owns it -- with the
     // owner's pixel, weight records and window statistics -- and the owner collects the costs in ascending view order, exactly
     // the sums of the uncompacted loop.  38 -> 25 evaluation rounds per wave and update on the cfg-1 scene.
-    float cpl[5 * 4], tcs[5], tgs[5];
+    //   * a masked prior pixel accepts a candidate when exp(-tc^2 / beta) * prior_term > restricted_cost (ref .cu:707), and
+    //     restricted_cost is 0 unless a neighbour was accepted above (a reference quirk, SURVEY a-10 iv).  With 0 on the right the
+    //     test does not depend on the cost at all: tc lies in [0, 2], so the exponential is a positive normal number, and the
+    //     prior term is either >= 0.5 or NaN (acos of a dot product beyond 1).  Every in-range candidate with a valid prior
+    //     term is therefore accepted in turn, each overwriting the one before: only the LAST of them leaves a trace, the
+    //     evaluations of all the others are dead.
+    float cpl[5 * 4], tcs[5], tgs[5], pr5[5];
 #ifndef PM_PARK_CPL_WHEN
 #define PM_PARK_CPL_WHEN true
 #endif
@@ -596,14 +602,38 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
 #pragma unroll
     for (int ci = 0; ci < 5; ++ci) {
         const int ni = 3 * ((ci == 1 || ci == 2) ? 1 : (ci == 3 ? 2 : 0));
+        const float cd = park_d[(ci == 0 || ci == 2) ? 1 : (ci == 4 ? 2 : 0)];
         float4 pl;
         pl.x = park_n[ni], pl.y = park_n[ni + 1], pl.z = park_n[ni + 2];
-        pl.w = plane_offset(P, x, y, park_d[(ci == 0 || ci == 2) ? 1 : (ci == 4 ? 2 : 0)], pl);
+        pl.w = plane_offset(P, x, y, cd, pl);
         cpl[4 * ci] = pl.x, cpl[4 * ci + 1] = pl.y, cpl[4 * ci + 2] = pl.z, cpl[4 * ci + 3] = pl.w;
         const float db = depth_from_plane(P, pl, x, y);
         if (!(db >= a.depth_min && db <= a.depth_max)) dead |= 1u << ci;
         tcs[ci] = 0.0f;
         tgs[ci] = 0.0f;
+        pr5[ci] = 0.0f;
+        if (PRIOR && masked) {
+            const float ac = (pp.x * pl.x + pp.y * pl.y) + pp.z * pl.z;
+            pr5[ci] = prior_term<kPriorCall>(cd - depth_prior, ac, two_ds2, two_as2);
+        }
+    }
+    if (PRIOR && masked) {
+        if (restricted_cost == 0.0f) {
+            int last = -1;
+#pragma unroll
+            for (int ci = 0; ci < 5; ++ci)
+                if (!((dead >> ci) & 1u) && pr5[ci] > 0.0f) last = ci;  // NaN > 0 is false
+            dead = last >= 0 ? (31u & ~(1u << last)) : 31u;
+        } else {
+            //   * ... and where a neighbour's acceptance has raised restricted_cost, a candidate whose prior term alone is not
+            //     above it cannot pass either: exp(-tc^2 / beta) <= 1 up to the 2 ulp of d_exp, so the product stays below
+            //     prior_term * (1 + 3e-7) < fl(prior_term * 1.000001) <= restricted_cost whatever tc turns out to be (a NaN
+            //     prior term fails the reference's test as it fails this one).  71-76 % of the candidates of a masked pixel
+            //     (tools/prune_stats.py --prior): random depths and normals sit far from the prior plane.
+#pragma unroll
+            for (int ci = 0; ci < 5; ++ci)
+                if (!(pr5[ci] * 1.000001f > restricted_cost)) dead |= 1u << ci;
+        }
     }
     // T: the exact product cost_now * weight_norm rounded up (the fp32 product is within half an ulp of it; one ulp more is
     // above it; both factors are finite and >= 0).  Masked prior pixels accept on another criterion (ref .cu:707): no threshold.
@@ -695,10 +725,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
         const float tc = tcs[ci] / weight_norm;
         const float tg = GEOM ? tgs[ci] / weight_norm : 0.0f;
         if (masked) {
-            cand_depth = park_d[(ci == 0 || ci == 2) ? 1 : (ci == 4 ? 2 : 0)];
-            const float ac = (pp.x * pl.x + pp.y * pl.y) + pp.z * pl.z;
-            const float pr = prior_term<kPriorCall>(cand_depth - depth_prior, ac, two_ds2, two_as2);
-            const float rtc = d_exp(-tc * tc / beta) * pr;
+            const float rtc = d_exp(-tc * tc / beta) * pr5[ci];
             if (rtc > restricted_cost) {
                 plane_now = pl;
                 cost_now = tc;

@@ -953,6 +953,20 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
         }
         const float depths5[5] = {depth_rand, depth_now, depth_rand, depth_now, depth_pert};
         const F4 normals5[5] = {plane_now, n_rand, n_rand, n_pert, plane_now};
+        // statistics hook, masked prior pixels with restricted_cost == 0: every in-range candidate with a valid prior term is
+        // accepted in turn (the test does not depend on the cost), so only the last of them leaves a trace
+        int stat_last_masked = -2;  // -2: the rule does not apply
+        if (g_stat_death && masked && restricted_cost == 0.0f) {
+            stat_last_masked = -1;
+            for (int i = 0; i < 5; ++i) {
+                F4 tp = normals5[i];
+                tp.w = plane_offset(cam, px, py, depths5[i], tp);
+                const float dbs = depth_from_plane(cam, tp, px, py);
+                const float ac = (pp.x * tp.x + pp.y * tp.y) + pp.z * tp.z;
+                const float pr = prior_term(depths5[i] - depth_prior, ac, two_ds2, two_as2);
+                if (dbs >= prm.depth_min && dbs <= prm.depth_max && pr > 0.0f) stat_last_masked = i;
+            }
+        }
         for (int i = 0; i < 5; ++i) {
             F4 tp = normals5[i];
             tp.w = plane_offset(cam, px, py, depths5[i], tp);
@@ -962,6 +976,12 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
             for (int v = 0; v < V; ++v) cv[v] = ncc_cost(c, rw, px, py, m, v);
             float tc = 0.0f, tg = 0.0f;
             int stat_death = V;
+            const float tp_plane_x = tp.x, tp_plane_y = tp.y, tp_plane_z = tp.z;
+            if (g_stat_death && masked && restricted_cost > 0.0f) {  // before any view: the prior term alone may already be too small
+                const float ac0 = (pp.x * tp.x + pp.y * tp.y) + pp.z * tp.z;
+                const float pr0 = prior_term(depths5[i] - depth_prior, ac0, two_ds2, two_as2);
+                if (!(pr0 * 1.000001f > restricted_cost)) stat_death = -1;
+            }
             const float stat_cost_start = cost_now_at_refinement_start;
             for (int v = 0; v < V; ++v) {
                 if (view_w[v] > 0.0f) {
@@ -973,11 +993,24 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
                         tc += view_w[v] * cv[v];
                     }
                     if (stat_death == V && !masked && tc / weight_norm >= stat_cost_start) stat_death = v;
+                    if (stat_death == V && masked && restricted_cost > 0.0f && g_stat_death && !getenv("NO_STEP_RULE")) {
+                        // masked prior pixel with a raised restricted cost: the final test exp(-tc^2 / beta) * prior_term >
+                        // restricted_cost is monotone in tc up to the 2 ulp of the exponential: once the running quotient gives
+                        // a value that is below restricted_cost with that margin, the candidate has lost
+                        const float tp = tc / weight_norm;
+                        const float ac0 = (pp.x * tp_plane_x + pp.y * tp_plane_y) + pp.z * tp_plane_z;
+                        const float pr0 = prior_term(depths5[i] - depth_prior, ac0, two_ds2, two_as2);
+                        const float f = det_exp(-tp * tp / beta) * pr0;
+                        if (!(f * 1.000001f > restricted_cost)) stat_death = v;
+                    }
                 }
             }
             if (g_stat_death) {
                 const float dbs = depth_from_plane(cam, tp, px, py);
-                g_stat_death[(size_t)idx * 5 + i] = (int8_t)((dbs >= prm.depth_min && dbs <= prm.depth_max) ? stat_death : -1);
+                int8_t dv = (int8_t)((dbs >= prm.depth_min && dbs <= prm.depth_max) ? stat_death : -1);
+                if (stat_death == -1) dv = -1;
+                if (stat_last_masked != -2) dv = (int8_t)(i == stat_last_masked ? V : -1);
+                g_stat_death[(size_t)idx * 5 + i] = dv;
             }
             tc /= weight_norm;
             if (geom) tg /= weight_norm;

@@ -23,7 +23,9 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (400, 304)
+    prior_mode = "--prior" in sys.argv
+    argv = [a for a in sys.argv if a != "--prior"]
+    W, H = (int(argv[1]), int(argv[2])) if len(argv) > 2 else (400, 304)
     V = 8
     pm = importlib.import_module("mp-mvs_amd")
     from oracle import binding as ob
@@ -39,7 +41,20 @@ def main():
     bad3 = np.zeros((H, W, 32), np.uint8)
     death = np.full((H, W, 5), -128, np.int8)
     wmask = np.zeros((H, W), np.uint32)
-    o.step(prm, 12345, pm.KIND_INIT, 0, 0, 0)
+    if prior_mode:
+        # the planar-prior Run() of the shipped schedule: a photometric Run(), the prior triangulated from it, then the launches
+        # of the prior Run() with the hook on
+        hostlib = importlib.import_module("mp-mvs_amd.hostlib")
+        o.run(prm, 12345)
+        planes, costs = o.get()
+        prior, mask, ntri = hostlib.build_prior(cams[0], planes, costs, None, False, prm.depth_min, prm.depth_max)
+        print(f"planar prior: {ntri} triangles, {float((mask > 0).mean()):.3f} of the pixels masked")
+        o.set_prior(prior, mask)
+        prm.planar_prior = True
+        seed0 = 777
+    else:
+        seed0 = 12345
+    o.step(prm, seed0, pm.KIND_INIT, 0, 0, 0)
     launch = 1
     yy, xx = np.mgrid[0:H, 0:W]
     print(f"{W}x{H}, {V} views; per launch: executed refinement steps per wave (of {5 * V} nominal)")
@@ -48,7 +63,7 @@ def main():
             death[...] = -128
             lib.orc_set_refinement_stats(death.ctypes.data, wmask.ctypes.data)
             lib.orc_set_propagation_stats(bad3.ctypes.data)
-            o.step(prm, 12345, kind, it, 0, launch)
+            o.step(prm, seed0, kind, it, 0, launch)
             lib.orc_set_refinement_stats(None, None)
             lib.orc_set_propagation_stats(None)
             launch += 1
