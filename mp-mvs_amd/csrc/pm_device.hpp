@@ -589,6 +589,9 @@ PM_DEV float ncc_core(const TEX& tex, float wf, float hf, float H0, float H1, fl
     // reciprocal between the six perspective divides, compute the
     // addresses and issue all gathers of the column back to back
     auto issue_column = [&](int a, BilinearTap<U8>(&tap)[6]) {
+#ifdef PM_SETPRIO_ISSUE  // measurement builds: the wave that is about to issue a column of gathers goes first
+        __builtin_amdgcn_s_setprio(PM_SETPRIO_ISSUE);
+#endif
         const float tx = (float)(px + a * step - radius);
         const float Cx = __builtin_fmaf(H0, tx, H2);
         const float Cy = __builtin_fmaf(H3, tx, H5);
@@ -615,6 +618,9 @@ PM_DEV float ncc_core(const TEX& tex, float wf, float hf, float H0, float H1, fl
             tap[2 * j].issue(tex, sx.x, sy.x);
             tap[2 * j + 1].issue(tex, sx.y, sy.y);
         }
+#ifdef PM_SETPRIO_ISSUE
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
     // phase 2: interpolate; the even taps (b = 0, 2, 4) and the odd taps of ALL columns accumulate in the two halves of packed
     // registers and meet once, at the end of the window

@@ -185,3 +185,65 @@ def test_run_get_geom_buffer_follows_the_reference_rule(pm, oracle, engine):
     g2 = np.empty((64, 96), np.float32)
     gpu.run_into(prm, 9, p, c, g2)
     assert np.array_equal(g2, g1)
+
+
+def test_set_src_depths_keeps_maps_passed_as_null(pm, engine):
+    """mpmvs_set_src_depths with NULL entries keeps the resident maps: uploading only the changed ones gives the state a full
+    upload gives (checked through the geometric-cost probe); a NULL without a resident map of that size is an error"""
+    _, fns = engine.load()
+    sc = pm.synth.make_problem_scene(96, 64, n_src=3, spacing=0.5, quantize=True)
+    cams, imgs = sc.problem(0, [1, 2, 3])
+    dmin, dmax = pm.synth.kernel_depth_range(cams[0])
+    prm = pm.PatchMatchParams(num_images=4, depth_min=float(dmin), depth_max=float(dmax), max_scale=0)
+    rng = np.random.default_rng(11)
+    d_old = [np.ascontiguousarray(sc.views[i].gt_depth * (1.0 + 0.01 * rng.standard_normal((64, 96))), np.float32) for i in (1, 2, 3)]
+    d_new1 = np.ascontiguousarray(sc.views[2].gt_depth * (1.0 + 0.02 * rng.standard_normal((64, 96))), np.float32)
+    planes = np.zeros((64, 96, 4), np.float32)
+    planes[..., 2] = -1.0
+    planes[..., 3] = sc.views[0].gt_depth
+    FP = C.POINTER(C.c_float)
+
+    def upload(ctx, maps):
+        ptrs = (FP * 3)(*[m.ctypes.data_as(FP) if m is not None else None for m in maps])
+        ws, hs = (C.c_int * 3)(96, 96, 96), (C.c_int * 3)(64, 64, 64)
+        return fns["set_src_depths"](ctx._ctx, 3, ptrs, ws, hs, None)
+
+    a = engine.create(0)
+    a.set_views(cams, imgs)
+    assert upload(a, [None, None, None]) != 0                      # nothing resident yet
+    assert upload(a, d_old) == 0
+    assert upload(a, [None, d_new1, None]) == 0                    # only source 1 changed
+    b = engine.create(0)
+    b.set_views(cams, imgs)
+    assert upload(b, [d_old[0], d_new1, d_old[2]]) == 0
+    ga, gb = a.eval_geom(prm, planes), b.eval_geom(prm, planes)
+    assert np.array_equal(ga, gb)
+    c0 = engine.create(0)
+    c0.set_views(cams, imgs)
+    assert upload(c0, d_old) == 0
+    assert not np.array_equal(c0.eval_geom(prm, planes)[1], ga[1])  # the changed map is really in use
+
+
+def test_pinned_host_buffers_round_trip(pm, engine):
+    """mpmvs_alloc_pinned / mpmvs_free_pinned: usable as the host arrays of mpmvs_run_get, pooled per size"""
+    _, fns = engine.load()
+    sc = pm.synth.make_problem_scene(96, 64, n_src=3, spacing=0.5, quantize=True)
+    cams, imgs = sc.problem(0, [1, 2, 3])
+    dmin, dmax = pm.synth.kernel_depth_range(cams[0])
+    prm = pm.PatchMatchParams(num_images=4, depth_min=float(dmin), depth_max=float(dmax), max_scale=0)
+    gpu = engine.create(0)
+    gpu.set_views(cams, imgs)
+    n = 64 * 96
+    p_planes, p_costs = fns["alloc_pinned"](n * 16), fns["alloc_pinned"](n * 4)
+    assert p_planes and p_costs
+    assert fns["run_get"](gpu._ctx, C.byref(prm), 5, p_planes, p_costs, None) == 0
+    planes = np.ctypeslib.as_array((C.c_float * (n * 4)).from_address(p_planes)).reshape(64, 96, 4).copy()
+    costs = np.ctypeslib.as_array((C.c_float * n).from_address(p_costs)).reshape(64, 96).copy()
+    gpu.run(prm, 5)
+    rp, rc = gpu.get()
+    assert np.array_equal(planes, rp) and np.array_equal(costs, rc)
+    fns["free_pinned"](p_planes)
+    again = fns["alloc_pinned"](n * 16)
+    assert again == p_planes                                        # handed out again from the pool
+    fns["free_pinned"](again)
+    fns["free_pinned"](p_costs)
