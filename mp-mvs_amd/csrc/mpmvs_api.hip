@@ -14,6 +14,8 @@
 // There is no per-pixel RNG state (the reference keeps 48 B/pixel of cuRAND).
 #include <hip/hip_runtime.h>
 
+#include <pthread.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -347,8 +349,17 @@ class RowPool {
         wake.notify_all();
         for (std::thread& t : workers) t.join();
     }
+    // a forked child inherits this object but not its threads: it works on its own thread
+    static std::atomic<bool>& forked() {
+        static std::atomic<bool> f(false);
+        return f;
+    }
     // fn() on every worker and on the caller (fn pulls its own work items from a shared counter)
     void run(const std::function<void()>& fn) {
+        if (forked().load(std::memory_order_relaxed)) {
+            fn();
+            return;
+        }
         if (!busy.try_lock()) {
             std::vector<std::thread> tmp;
             for (int t = 0; t < 3; ++t) tmp.emplace_back(fn);
@@ -370,6 +381,8 @@ class RowPool {
 };
 RowPool& row_pool() {
     static RowPool p;
+    static const int registered = pthread_atfork(nullptr, nullptr, [] { RowPool::forked().store(true); });
+    (void)registered;
     return p;
 }
 

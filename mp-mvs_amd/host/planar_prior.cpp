@@ -244,6 +244,11 @@ int HostThreads() {
 HostPool* AcquireSharedPool() {
     static std::mutex mu;
     static std::unique_ptr<HostPool> pool;
+    // a forked child inherits the pool object but not its threads: it triangulates on its own thread
+    static std::atomic<bool> forked(false);
+    static const int registered = pthread_atfork(nullptr, nullptr, [] { forked.store(true); });
+    (void)registered;
+    if (forked.load(std::memory_order_relaxed)) return nullptr;
     std::lock_guard<std::mutex> lk(mu);
     const int want = HostThreads();
     if (want < 2) return nullptr;

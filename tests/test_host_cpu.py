@@ -479,3 +479,31 @@ def test_unassigned_cell_points_are_pixel_zero(hostlib):
     assert hostlib.triangulate_vertices(costs, geom, True).tolist() == [[0, 0], [0, 0], [0, 0]]
     costs[7, 8] = 0.1
     assert hostlib.triangulate_vertices(costs, geom, True).tolist() == [[0, 0], [0, 0], [0, 0], [8, 7]]
+
+
+def test_delaunay_in_a_forked_child(hostlib):
+    """the persistent thread pool of the triangulation does not survive a fork: the child must notice and run on its own
+    thread instead of waiting for workers it does not have"""
+    rng = np.random.default_rng(0)
+    pts = rng.integers(0, 2000, size=(9000, 2)).astype(np.int32)
+    ref = np.array(hostlib.delaunay(2000, 2000, pts))           # creates the pool in this process
+    pid = os.fork()
+    if pid == 0:
+        try:
+            ok = np.array_equal(ref, np.array(hostlib.delaunay(2000, 2000, pts)))
+        except BaseException:
+            ok = False
+        os._exit(0 if ok else 3)
+    deadline = 60.0
+    import time
+    t0 = time.time()
+    while True:
+        done, status = os.waitpid(pid, os.WNOHANG)
+        if done:
+            break
+        if time.time() - t0 > deadline:
+            os.kill(pid, 9)
+            os.waitpid(pid, 0)
+            raise AssertionError("the forked child hung in the triangulation")
+        time.sleep(0.05)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
