@@ -157,7 +157,7 @@ class HostPool {
     std::mutex mu;
     std::condition_variable wake;
     std::function<void(int)> job;
-    std::atomic<int> next{0}, remaining{0};
+    std::atomic<int> next{0}, running{0};
     int ntasks = 0;
     unsigned long generation = 0;
     bool quit = false;
@@ -168,7 +168,6 @@ class HostPool {
             const int i = next.fetch_add(1, std::memory_order_relaxed);
             if (i >= ntasks) return;
             job(i);
-            remaining.fetch_sub(1, std::memory_order_release);
         }
     }
     void worker(int slot, std::vector<int> cpus) {
@@ -187,6 +186,7 @@ class HostPool {
                 seen = generation;
             }
             claim_and_run();
+            running.fetch_sub(1, std::memory_order_release);  // this worker has left the sweep
         }
     }
 
@@ -225,12 +225,14 @@ class HostPool {
             job = fn;
             ntasks = n;
             next.store(0, std::memory_order_relaxed);
-            remaining.store(n, std::memory_order_relaxed);
+            running.store((int)workers.size(), std::memory_order_relaxed);
             ++generation;
         }
         wake.notify_all();
         claim_and_run();
-        while (remaining.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+        // every worker takes part in every sweep and reports when it has left it: when this returns no thread is still looking
+        // at this sweep's job or counters (a worker that wakes late must not meet the next sweep's parameters half-way)
+        while (running.load(std::memory_order_acquire) > 0) std::this_thread::yield();
     }
 };
 
