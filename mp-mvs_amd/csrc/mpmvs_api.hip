@@ -1614,6 +1614,7 @@ int mpmvs_sky_bilateral(int device, const unsigned char* bgr, const float* mask,
 
 void* mpmvs_alloc_pinned(size_t bytes) {
     if (bytes == 0) bytes = 4;
+    static const bool trace = std::getenv("MPMVS_TRACE_PINNED") != nullptr;  // debugging aid: pool hits and misses on stderr
     {
         std::lock_guard<std::mutex> lk(g_pinned.mu);
         auto it = g_pinned.cached.find(bytes);
@@ -1621,11 +1622,13 @@ void* mpmvs_alloc_pinned(size_t bytes) {
             void* p = it->second.back();
             it->second.pop_back();
             g_pinned.cached_bytes -= bytes;
+            if (trace) std::fprintf(stderr, "[mpmvs] pinned %zu B: from the pool\n", bytes);
             return p;
         }
     }
     void* p = nullptr;
     (void)hipGetLastError();
+    if (trace) std::fprintf(stderr, "[mpmvs] pinned %zu B: hipHostMalloc\n", bytes);
     if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;

@@ -244,6 +244,10 @@ void ProcessProblem(std::vector<Scene>& Scenes, const int ID, bool geom_consiste
 
 // ---- planar prior construction (planar_prior.cpp), usable without a device ----
 namespace mpmvs_host {
+// Threads for the library's OpenMP loops: min(16, hardware threads), MPMVS_HOST_THREADS overrides.  Never the OpenMP default:
+// on a many-core host inside a container with a CPU quota (256 hardware threads, 16 CPUs of quota on the target boxes) a
+// 256-thread team spins its quota away after every loop and the whole process is throttled for tens of milliseconds.
+int OmpThreads();
 // reference src/PatchMatch.cpp:782-853
 void TriangulateVertices(int width, int height, const float* costs, const float* geom_costs, bool geomPlanarPrior,
                          std::vector<Point>& Vertices);

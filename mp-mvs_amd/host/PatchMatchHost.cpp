@@ -263,7 +263,7 @@ void PatchMatchCUDA::CudaMemInit(Scene& scene) {
         if (!state_resident) {
             const Image &sn = scene.normal, &sd = scene.depth, &sc = scene.cost;
             const int width = sd.cols, height = sd.rows;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(mpmvs_host::OmpThreads()) schedule(static)
             for (int row = 0; row < height; ++row)
                 for (int col = 0; col < width; ++col) {
                     const size_t idx = (size_t)row * width + col;
@@ -283,7 +283,7 @@ void PatchMatchCUDA::CudaPlanarPriorInitialization(const std::vector<float4>& Pl
     hostPriorPlanes.allocate((size_t)W * H);
     hostPlaneMask.allocate((size_t)W * H);
     tm.lap("  prior: resize");
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(mpmvs_host::OmpThreads()) schedule(static)
     for (int i = 0; i < H; ++i)
         for (int j = 0; j < W; ++j) {
             const size_t idx = (size_t)i * W + j;
@@ -305,7 +305,7 @@ void PatchMatchCUDA::CudaPlanarPriorInitialization(const std::vector<Triangle>& 
     // fallback for a caller's own triangle list
     const size_t n = triangles.size();
     bool all_inside = true;
-#pragma omp parallel for schedule(static) reduction(&& : all_inside)
+#pragma omp parallel for num_threads(mpmvs_host::OmpThreads()) schedule(static) reduction(&& : all_inside)
     for (long i = 0; i < (long)n; ++i) {
         const Triangle& t = triangles[(size_t)i];
         all_inside = all_inside && imageRC.contains(t.pt1) && imageRC.contains(t.pt2) && imageRC.contains(t.pt3);
@@ -495,7 +495,7 @@ void ProcessProblem(std::vector<Scene>& Scenes, const int ID, bool geom_consiste
     const float4* host_planes = MP.GetPlaneHypotheses();
     const float* host_costs = MP.GetCosts();
     float *pd = out.depth.data.data(), *pn = out.normal.data.data(), *pc = out.cost.data.data();
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(mpmvs_host::OmpThreads()) schedule(static)
     for (int row = 0; row < height; ++row)
         for (int col = 0; col < width; ++col) {
             const size_t idx = (size_t)row * width + col;

@@ -2,6 +2,10 @@
 // (sequential and progressive) with libjpeg-compatible reconstruction arithmetic.
 #include "jpeg_decode.h"
 
+namespace mpmvs_host {
+int OmpThreads();  // planar_prior.cpp: min(16, hardware threads), never the OpenMP default (PatchMatch.h)
+}
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -529,7 +533,7 @@ void Decoder::reconstruct() {
         if (!k.q_latched) {
             std::memset(k.q, 0, sizeof(k.q));
         }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(mpmvs_host::OmpThreads()) schedule(static)
         for (int by = 0; by < k.hb; ++by)
             for (int bx = 0; bx < k.wb; ++bx) idct_islow(&k.coef[((size_t)by * k.wb + bx) * 64], k.q, &k.plane[(size_t)by * 8 * stride + bx * 8], stride);
     }
@@ -557,7 +561,7 @@ void upsample(const Comp& k, int hmax, int vmax, int W, int H, std::vector<uint8
             }
         }
     } else if (fh == 2 && fv == 2 && k.cw > 2) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(mpmvs_host::OmpThreads()) schedule(static)
         for (int y = 0; y < H; ++y) {
             const int r = y >> 1;
             const uint8_t* s0 = row(r);
@@ -739,7 +743,7 @@ bool DecodeJpeg(const uint8_t* data, size_t size, int channels, std::vector<uint
         cb_g[i] = -fix(0.34414) * x + 32768;
     }
     auto clamp8 = [](int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); };
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(mpmvs_host::OmpThreads()) schedule(static)
     for (int r = 0; r < H; ++r) {
         for (int c = 0; c < W; ++c) {
             const size_t i = (size_t)r * W + c;

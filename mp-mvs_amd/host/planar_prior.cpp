@@ -38,6 +38,11 @@
 #include "PatchMatch.h"
 
 namespace mpmvs_host {
+int OmpThreads() {
+    if (const char* e = std::getenv("MPMVS_HOST_THREADS")) return std::max(1, std::atoi(e));
+    const unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::min(16u, std::max(1u, hc));
+}
 
 // ---------------------------------------------------------------------------
 // vertices: the image is cut into 5x5-pixel cells (smaller at the right / bottom border) and every cell may contribute its
@@ -722,7 +727,7 @@ void BuildPrior(const Camera& cam, int width, int height, const std::vector<Tria
     // reference's sequential loop = the largest label: an atomic max over triangles
     // processed in parallel gives the same mask.
     std::vector<uint32_t> label((size_t)width * height, 0u);
-#pragma omp parallel for schedule(dynamic, 256)
+#pragma omp parallel for num_threads(mpmvs_host::OmpThreads()) schedule(dynamic, 256)
     for (long k = 0; k < (long)keep.size(); ++k) {
         const Triangle& t = triangles[keep[k]];
         const uint32_t lab = (uint32_t)k + 1u;
@@ -748,7 +753,7 @@ void BuildPrior(const Camera& cam, int width, int height, const std::vector<Tria
         planeParams[k] = PriorPlane(cam, t, planes, width);
     }
     mask = Image(height, width, 1, 0.0f);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(mpmvs_host::OmpThreads()) schedule(static)
     for (int j = 0; j < height; ++j)
         for (int i = 0; i < width; ++i) {
             const uint32_t lab = label[(size_t)j * width + i];

@@ -363,7 +363,7 @@ int RunFolderJacobi(const std::string& input_folder, int max_src, int max_image_
             for (int id : s.srcID)
                 if (id >= 0 && id < n) needed[id] = 1;
     std::atomic<bool> ok(true);
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for num_threads(mpmvs_host::OmpThreads()) schedule(dynamic, 1)
     for (int i = 0; i < n; ++i) {
         if (!needed[i]) continue;
         Scene& s = Scenes[i];
