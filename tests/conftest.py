@@ -33,6 +33,8 @@ def pm():
 def oracle():
     from oracle import binding
     binding.build()
+    # the GPU boxes show 256 hardware threads to a container with 16 CPUs of quota: an OpenMP team of 256 is throttled
+    binding.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     return binding
 
 
