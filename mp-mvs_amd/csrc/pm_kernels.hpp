@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
     //     are monotone, and cost_now only decreases from one candidate to the next: once a candidate's running sum has reached
     //     T >= cost_now * weight_norm (exact product, rounded UP) with the cost_now the refinement started with, its quotient
     //     is >= that cost_now whatever the remaining views add -- they are dead work the reference performs (:681) and nothing
-    //     reads.  (Measured with the oracle's statistics hook, tools/prune_stats.py: 45 % of a lane's refinement evaluations.)
+    //     reads.  (Measured with the oracle's statistics hook, tests/analysis/prune_stats.py: 45 % of a lane's refinement evaluations.)
     // A lane cannot profit from its own dead evaluations while other lanes of the wave are still live, so the live (pixel,
     // candidate) pairs of a view are DEALT TO THE LANES OF THE WAVE through LDS: every lane publishes the planes of its live
     // candidates at consecutive slots (ballot + mbcnt), lane j evaluates item j of the round for whoever owns it -- with the
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
             //     above it cannot pass either: exp(-tc^2 / beta) <= 1 up to the 2 ulp of d_exp, so the product stays below
             //     prior_term * (1 + 3e-7) < fl(prior_term * 1.000001) <= restricted_cost whatever tc turns out to be (a NaN
             //     prior term fails the reference's test as it fails this one).  71-76 % of the candidates of a masked pixel
-            //     (tools/prune_stats.py --prior): random depths and normals sit far from the prior plane.
+            //     (tests/analysis/prune_stats.py --prior): random depths and normals sit far from the prior plane.
 #pragma unroll
             for (int ci = 0; ci < 5; ++ci)
                 if (!(pr5[ci] * 1.000001f > restricted_cost)) dead |= 1u << ci;

@@ -674,7 +674,7 @@ inline float prior_term(float depth_diff, float angle_cos, float two_ds2, float 
     return 0.5f + det_exp(-depth_diff * depth_diff / two_ds2) * det_exp(-ad * ad / two_as2);
 }
 
-// Statistics hook for sizing kernel optimisations (tools/prune_stats.py): when set, every update_pixel records, per
+// Statistics hook for sizing kernel optimisations (tests/analysis/prune_stats.py): when set, every update_pixel records, per
 // refinement candidate, after how many views (ascending view index) its running weighted sum has provably lost against the
 // cost the refinement started from -- i.e. which evaluations of the refinement nothing reads.  The oracle itself always
 // evaluates everything (ref .cu:681).  g_stat_death[idx * 5 + i]: -1 = depth out of range (dead from the start), v = the
@@ -976,7 +976,6 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
             for (int v = 0; v < V; ++v) cv[v] = ncc_cost(c, rw, px, py, m, v);
             float tc = 0.0f, tg = 0.0f;
             int stat_death = V;
-            const float tp_plane_x = tp.x, tp_plane_y = tp.y, tp_plane_z = tp.z;
             if (g_stat_death && masked && restricted_cost > 0.0f) {  // before any view: the prior term alone may already be too small
                 const float ac0 = (pp.x * tp.x + pp.y * tp.y) + pp.z * tp.z;
                 const float pr0 = prior_term(depths5[i] - depth_prior, ac0, two_ds2, two_as2);
@@ -993,16 +992,6 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
                         tc += view_w[v] * cv[v];
                     }
                     if (stat_death == V && !masked && tc / weight_norm >= stat_cost_start) stat_death = v;
-                    if (stat_death == V && masked && restricted_cost > 0.0f && g_stat_death && !getenv("NO_STEP_RULE")) {
-                        // masked prior pixel with a raised restricted cost: the final test exp(-tc^2 / beta) * prior_term >
-                        // restricted_cost is monotone in tc up to the 2 ulp of the exponential: once the running quotient gives
-                        // a value that is below restricted_cost with that margin, the candidate has lost
-                        const float tp = tc / weight_norm;
-                        const float ac0 = (pp.x * tp_plane_x + pp.y * tp_plane_y) + pp.z * tp_plane_z;
-                        const float pr0 = prior_term(depths5[i] - depth_prior, ac0, two_ds2, two_as2);
-                        const float f = det_exp(-tp * tp / beta) * pr0;
-                        if (!(f * 1.000001f > restricted_cost)) stat_death = v;
-                    }
                 }
             }
             if (g_stat_death) {

@@ -2,7 +2,7 @@
 """fusion throughput on one GPU: 8 images of 1600x1200 (ground-truth maps + noise), GPU vs oracle"""
 import importlib, json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa

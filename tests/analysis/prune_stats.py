@@ -10,7 +10,7 @@ aggregates, per update launch, the (view, candidate) steps of the refinement at 
   compacted  every lane walks its own list of live candidates of the view; trips = longest list in the wave
   cross-lane the live (pixel, candidate) items of a view are dealt to the 64 lanes; trips = ceil(items / 64)
 
-CPU only (test infrastructure); usage: python tools/prune_stats.py [W H]"""
+CPU only (test infrastructure); usage: python tests/analysis/prune_stats.py [W H]"""
 import ctypes as C
 import importlib
 import os
@@ -18,7 +18,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

@@ -2,14 +2,14 @@
 """Would a per-(pixel, candidate slot) cache of phase-A costs hit?  A cost is a pure function of (pixel, plane, view, window
 scale): if the candidate a slot picks is the same neighbour as at the pixel's previous update AND that neighbour's plane has
 not changed a bit since, the V evaluations of the slot could be reused exactly.  Measured on the CPU oracle, cfg-1 schedule.
-usage: python tools/reuse_stats.py [W H] [iterations]"""
+usage: python tests/analysis/reuse_stats.py [W H] [iterations]"""
 import importlib
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 DIRS = [

@@ -4,7 +4,7 @@ host planar prior + prior Run -> geometric Run) on one 1600x1200 Problem with 8 
 HIP path against the same schedule driven on the CPU oracle.  Takes a few minutes of host time."""
 import importlib, json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa
