@@ -541,9 +541,19 @@ struct BilinearTap<true> {
         const float cy = clamp_coord(sy, t.hm1);
         ax = __builtin_amdgcn_fractf(cx);
         ay = __builtin_amdgcn_fractf(cy);
-        const int idx = texel_index(t, floor_to_int(cy), floor_to_int(cx));
+        [[maybe_unused]] const int idx = texel_index(t, floor_to_int(cy), floor_to_int(cx));
 #ifdef PM_DBG_NOLOAD  // measurement builds only (results are wrong): the instruction stream without its gathers
         q = (u32x2q){(uint32_t)idx, (uint32_t)idx};
+#elif defined(PM_DBG_LDSTEX)
+        // measurement builds only (results are wrong): what a tile-resident texel would cost per tap -- tile-relative coordinates
+        // (two subtractions), the out-of-tile accumulator (two ORs), a byte address and an 8-byte LDS read from the exchange area
+        {
+            const float rx = cx - 16.0f, ry = cy - 8.0f;
+            int irx = floor_to_int(rx), iry = floor_to_int(ry);
+            asm volatile("v_or_b32 %0, %0, %1\n\tv_or_b32 %1, %1, %0" : "+v"(irx), "+v"(iry));  // stands in for the two accumulator ORs
+            const unsigned a = ((unsigned)(iry * 32 + irx) << 3) & 8184u;
+            q = *reinterpret_cast<const u32x2q*>(reinterpret_cast<const char*>(pm_lds + kLdsWeightFloats) + a);
+        }
 #else
         q = pm_struct_load_b64(t.irsrc, idx, 0, 0, 0);
 #endif
