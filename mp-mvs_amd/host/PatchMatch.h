@@ -248,6 +248,8 @@ namespace mpmvs_host {
 // on a many-core host inside a container with a CPU quota (256 hardware threads, 16 CPUs of quota on the target boxes) a
 // 256-thread team spins its quota away after every loop and the whole process is throttled for tens of milliseconds.
 int OmpThreads();
+// a schedule that drives k Problems from k host threads at once (RunFolderJacobi) says so: each caller's loops then take 1/k of the threads
+void SetConcurrentCallers(int k);
 // reference src/PatchMatch.cpp:782-853
 void TriangulateVertices(int width, int height, const float* costs, const float* geom_costs, bool geomPlanarPrior,
                          std::vector<Point>& Vertices);

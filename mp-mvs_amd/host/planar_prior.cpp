@@ -38,10 +38,17 @@
 #include "PatchMatch.h"
 
 namespace mpmvs_host {
+static std::atomic<int> g_concurrent_callers{1};
+void SetConcurrentCallers(int k) { g_concurrent_callers.store(k < 1 ? 1 : k); }
 int OmpThreads() {
-    if (const char* e = std::getenv("MPMVS_HOST_THREADS")) return std::max(1, std::atoi(e));
-    const unsigned hc = std::thread::hardware_concurrency();
-    return (int)std::min(16u, std::max(1u, hc));
+    int base;
+    if (const char* e = std::getenv("MPMVS_HOST_THREADS")) {
+        base = std::max(1, std::atoi(e));
+    } else {
+        const unsigned hc = std::thread::hardware_concurrency();
+        base = (int)std::min(16u, std::max(1u, hc));
+    }
+    return std::max(1, base / g_concurrent_callers.load(std::memory_order_relaxed));
 }
 
 // ---------------------------------------------------------------------------

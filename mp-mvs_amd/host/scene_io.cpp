@@ -382,8 +382,13 @@ int RunFolderJacobi(const std::string& input_folder, int max_src, int max_image_
     for (int i = 0; i < n; ++i)
         if (Scenes[i].estimate) todo.push_back(i);
     const int nworkers = std::max(1, std::min(workers, (int)todo.size()));
+    // the maps a pass replaces become the storage of the pass after the next (ProcessProblem keeps buffers of the right size):
+    // after the first two passes no pass allocates or page-faults fresh result memory
+    std::vector<ProblemResult> spare(n);
+    mpmvs_host::SetConcurrentCallers(nworkers);
     auto run_pass = [&](bool geom, bool pp, uint64_t pass_seed) {
         std::vector<ProblemResult> results(n);
+        for (int i : todo) results[i] = std::move(spare[i]);
         std::atomic<size_t> next(0);
         auto work = [&](int) {
             for (;;) {
@@ -406,13 +411,15 @@ int RunFolderJacobi(const std::string& input_folder, int max_src, int max_image_
         for (std::thread& t : pool) t.join();
         // the barrier of the pass: only now do the new maps become what the next pass reads
         for (int i : todo) {
-            Scenes[i].depth = std::move(results[i].depth);
-            Scenes[i].normal = std::move(results[i].normal);
-            Scenes[i].cost = std::move(results[i].cost);
+            std::swap(Scenes[i].depth, results[i].depth);
+            std::swap(Scenes[i].normal, results[i].normal);
+            std::swap(Scenes[i].cost, results[i].cost);
+            spare[i] = std::move(results[i]);  // the maps of the pass before: storage for the pass after the next
         }
     };
     run_pass(false, !geomPlanarPrior && planar_prior, seed);
     for (int g = 0; g < geom_iterations; ++g) run_pass(true, geomPlanarPrior && g != geom_iterations - 1, seed + 100003ull * (g + 1));
+    mpmvs_host::SetConcurrentCallers(1);
     if (in_memory) {
         in_memory->assign(n, ProblemResult());
         for (int i : todo) {
