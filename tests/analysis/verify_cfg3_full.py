@@ -20,7 +20,7 @@ src_depths = [gt * (1.0 + 0.005 * rng.standard_normal(gt.shape)).astype(np.float
 t0 = time.perf_counter()
 depth, normal, cost = hostlib.run_pipeline(0, cams, imgs, 2, 2, True, True, 4242, src_depths)
 t_gpu = time.perf_counter() - t0
-ob.set_num_threads(min(64, len(os.sched_getaffinity(0))))
+ob.set_num_threads(min(16, len(os.sched_getaffinity(0))))
 t0 = time.perf_counter()
 planes, costs = oracle_pipeline(pm, ob, hostlib, cams, imgs, src_depths, 2, 2, True, True, 4242)
 t_cpu = time.perf_counter() - t0
