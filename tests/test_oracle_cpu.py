@@ -377,3 +377,43 @@ def test_end_to_end_statistics_canonical_vs_literal(pm, oracle):
     for mode in (1, 2):
         assert abs(stats[mode][0] - stats[0][0]) < 0.02 and abs(stats[mode][1] - stats[0][1]) < 0.02, stats
         assert abs(stats[mode][2] / stats[0][2] - 1.0) < 0.02, stats
+
+
+def test_refinement_rejection_rules_hold_in_fp32(pm, oracle):
+    """The arithmetic facts behind the exact early rejection of refinement candidates in k_update (pm_kernels.hpp; DESIGN.md
+    section 5), checked on random data in the very fp32 operations the kernel and the oracle use.
+
+    (1) Non-masked pixels: terms w * c are >= 0 and summed in sequence; T = fl(cost * norm) + 1 ulp.  Whenever a partial sum has
+        reached T, the final quotient fl(sum / norm) is >= cost, i.e. the reference's `tc < cost_now` is false.
+    (2) Masked prior pixels with a raised restricted cost rc: whenever fl(pr * 1.000001) <= rc, the reference's
+        `exp(-tc^2 / beta) * pr > rc` is false for every tc in [0, 2.6] (the canonical exp is within 2 ulp and <= 1 + 2 ulp there)."""
+    rng = np.random.default_rng(42)
+    f32 = np.float32
+    n, V = 200000, 8
+    w = rng.integers(0, 5, size=(n, V)).astype(f32)
+    w[:, 0] = np.maximum(w[:, 0], 1)
+    c = (rng.uniform(0.0, 2.0, size=(n, V)) ** rng.choice([1.0, 3.0], size=(n, 1))).astype(f32)
+    norm = w.sum(1, dtype=f32)
+    cost = rng.uniform(0.0, 1.2, n).astype(f32)
+    T = (cost * norm).view(np.uint32) + np.uint32(1)
+    T = T.view(f32)
+    s = np.zeros(n, f32)
+    reached = np.zeros(n, bool)
+    for v in range(V):
+        s = (s + w[:, v] * c[:, v]).astype(f32)
+        reached |= s >= T
+    tc = (s / norm).astype(f32)
+    assert reached.any() and (~reached).any()
+    assert not (tc[reached] < cost[reached]).any()
+    # (2)
+    beta = f32(0.18)
+    pr = rng.uniform(0.5, 1.5, n).astype(f32)
+    rc = (pr * rng.uniform(0.98, 1.02, n)).astype(f32)                    # right around the prior term: the interesting zone
+    tcs = np.concatenate([np.zeros(n // 2, f32), rng.uniform(0.0, 2.6, n - n // 2).astype(f32)])
+    x = (-(tcs * tcs) / beta).astype(f32)
+    e = pm._abi.math_probe(oracle.fns(), 1, x)
+    rtc = (e * pr).astype(f32)
+    dead = ~((pr * f32(1.000001)).astype(f32) > rc)
+    assert dead.any() and (~dead).any()
+    assert not (rtc[dead] > rc[dead]).any()
+    assert e.max() <= np.nextafter(np.nextafter(f32(1.0), f32(2.0)), f32(2.0))
