@@ -507,3 +507,24 @@ def test_delaunay_in_a_forked_child(hostlib):
             raise AssertionError("the forked child hung in the triangulation")
         time.sleep(0.05)
     assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+
+
+@pytest.mark.parametrize("kind", ["uniform", "band"])
+def test_delaunay_large_sets_agree_across_thread_counts(hostlib, monkeypatch, kind):
+    """60-70 k points (the level-by-level driver with 32 - 64 subtrees): the same triangulation on 1, 8 and 3 threads -- also
+    for a band whose cuts along y meet only a dozen distinct coordinate values"""
+    rng = np.random.default_rng(7)
+    if kind == "uniform":
+        pts = np.stack([rng.integers(0, 1600, 70000), rng.integers(0, 1200, 70000)], -1).astype(np.int32)
+    else:
+        pts = np.stack([rng.integers(0, 4000, 60000), rng.integers(0, 12, 60000)], -1).astype(np.int32)
+    ref = None
+    for threads in ("1", "8", "3"):
+        monkeypatch.setenv("MPMVS_HOST_THREADS", threads)
+        tris = np.array(hostlib.delaunay(4096, 4096, pts))
+        if ref is None:
+            ref = tris
+            uniq = np.unique(pts, axis=0)
+            assert len(tris) <= 2 * len(uniq) and len(tris) >= len(uniq)
+        else:
+            assert np.array_equal(ref, tris), f"{threads} threads"
