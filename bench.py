@@ -16,8 +16,12 @@ over one reference-image Problem: 1 reference + 8 source views, 1600x1200, singl
 single-GPU configurations of BASELINE.json (cfg 2, cfg 3) and the two non-headline formats of cfg 1 (fp32 textures, 20 source
 views), each with its own k_update average and roofline fraction; `cpu_baseline` is the oracle on the host cores.
 
-Multi-GPU (--gpus N under torch.distributed.run): cfg 1 Problems are independent, one per rank per step, no data-path
-collective (weak scaling); RCCL only provides the barrier and the max-reduce of the time.
+Multi-GPU (--gpus N): one process per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process is
+one rank; started plainly (`python bench.py --gpus N`), it becomes a launcher that never touches the GPU: it starts N fresh child
+processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, forwards rank 0's JSON line and exits non-zero if any rank failed
+(no exec of a process that has initialised HIP).  cfg 1 Problems are independent, one per rank per step, no data-path collective
+(weak scaling); RCCL only provides the barrier and the max-reduce of the time.  With N > 1 the same invocation then runs
+configs[4] once (`secondary.cfg4`, below) so that one driver command also exercises the exchange.
 
 --workload cfg4 (BASELINE.json configs[4]): 64 reference-image Problems (8x8 camera grid, 8 nearest neighbours as sources)
 sharded over the ranks, the shipped schedule (photometric 3 scales -> geometric + planar prior -> geometric), ONE
@@ -109,51 +113,58 @@ def load_scene(pm, w, h, v, quantize):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def measured_traffic_bytes():
-    """HBM bytes per k_update launch (FETCH_SIZE + WRITE_SIZE, KiB at the L2's memory side) from the committed rocprofv3 PMC
-    passes of this same command (profiles/, collected with tools/profile_gpu.sh: PMC cannot be read in-process)"""
-    best = None
-    pdir = os.path.join(ROOT, "profiles")
-    if not os.path.isdir(pdir):
-        return None
-    for name in sorted(os.listdir(pdir)):
-        if not name.endswith(".txt") or "pmc_summary" not in name:
-            continue
-        vals, kern = {}, None
-        for line in open(os.path.join(pdir, name)):
-            t = line.strip()
-            if t.startswith("k_"):
-                kern = t.split()[0]
-            elif kern == "k_update" and (t.startswith("FETCH_SIZE") or t.startswith("WRITE_SIZE")):
-                vals[t.split()[0]] = float(t.split("avg=")[1])
-        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-            # last file in name order = latest round.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 128-byte requests at 64
-            # bytes (exactly half for wide coalesced streaming reads, to be doubled), other access widths are uncalibrated: this
-            # kernel's HBM reads are L2 misses of 8 / 16-byte gathers plus scratch refills, so the bytes lie between the raw sum
-            # (`traffic`) and the sum with FETCH_SIZE doubled (`traffic_if_fetch_doubled`)
-            best = ((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
-                    f"profiles/{name}: FETCH_SIZE + WRITE_SIZE per k_update launch of a committed rocprofv3 --pmc run of this command (PMC cannot be read in-process)")
-    return best
+KERNEL_SOURCES = ("mp-mvs_amd/csrc/pm_kernels.hpp", "mp-mvs_amd/csrc/pm_device.hpp", "mp-mvs_amd/csrc/mpmvs_api.hip", "mp-mvs_amd/csrc/Makefile")
 
 
-def profile_valu_busy():
-    """executed-work utilisation of the committed PMC run: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), per k_update launch"""
+def kernel_sources_sha256():
+    """identifies the kernel build a profile belongs to (tools/summarize_prof.py writes the same hash into its summary)"""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def profile_counters(upd_avg_ms):
+    """PMC figures of k_update from the latest committed `profiles/*pmc_summary*` file (rocprofv3 --pmc passes of this same
+    command, tools/profile_gpu.sh: PMC cannot be read in-process) -- but only if that profile describes THIS build and THIS
+    run: its recorded kernel-source hash must equal the tree's and its kernel-trace average of k_update must lie within 3 % of
+    the average this run measured with HIP events.  Otherwise every figure is None and `reason` says why.
+    FETCH_SIZE / WRITE_SIZE are KiB at the L2's memory side.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 128-byte
+    requests at 64 bytes (exactly half for wide coalesced streaming reads), other access widths are uncalibrated: this kernel's
+    reads are L2 misses of 8 / 16-byte gathers plus scratch refills, so the bytes lie between the raw sum (`traffic`) and the
+    sum with FETCH_SIZE doubled (`traffic_if_fetch_doubled`)."""
+    none = {"traffic": None, "traffic_if_fetch_doubled": None, "valu_busy": None, "source": None, "reason": None}
     pdir = os.path.join(ROOT, "profiles")
-    out = None
-    if not os.path.isdir(pdir):
-        return None
-    for name in sorted(os.listdir(pdir)):
-        if not name.endswith(".txt") or "pmc_summary" not in name:
-            continue
-        vals, kern = {}, None
-        for line in open(os.path.join(pdir, name)):
-            t = line.strip()
-            if t.startswith("k_"):
-                kern = t.split()[0]
-            elif kern == "k_update" and "avg=" in t:
-                vals[t.split()[0]] = float(t.split("avg=")[1])
-        if "SQ_ACTIVE_INST_VALU" in vals and "GRBM_GUI_ACTIVE" in vals:
-            out = {"value": round(vals["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * vals["GRBM_GUI_ACTIVE"] / 8.0), 4), "source": f"profiles/{name}"}
+    names = sorted(n for n in os.listdir(pdir) if n.endswith(".txt") and "pmc_summary" in n) if os.path.isdir(pdir) else []
+    if not names:
+        return dict(none, reason="no profiles/*pmc_summary*.txt")
+    name = names[-1]   # last in name order = latest round
+    vals, kern, meta, trace_avg = {}, None, {}, None
+    for line in open(os.path.join(pdir, name)):
+        t = line.strip()
+        if t.startswith("#") and ":" in t:
+            k, v = t[1:].split(":", 1)
+            meta[k.strip()] = v.strip()
+        elif t.startswith("k_update") and " avg " in t and trace_avg is None:
+            trace_avg = float(t.split(" avg ")[1].split()[0])
+        elif t.startswith("k_"):
+            kern = t.split()[0]
+        elif kern == "k_update" and "avg=" in t:
+            vals[t.split()[0]] = float(t.split("avg=")[1])
+    src = f"profiles/{name}"
+    if meta.get("kernel_sources_sha256") != kernel_sources_sha256():
+        return dict(none, source=src, reason=f"{src} was collected on another kernel build (sources hash {meta.get('kernel_sources_sha256')} != {kernel_sources_sha256()})")
+    if trace_avg is None or abs(trace_avg - upd_avg_ms) > 0.03 * upd_avg_ms:
+        return dict(none, source=src, reason=f"{src}: k_update averaged {trace_avg} ms there, {upd_avg_ms:.4f} ms in this run (more than 3 % apart)")
+    out = dict(none, source=src + f" (git {meta.get('git_head', '?')}, k_update trace average {trace_avg} ms; command: {meta.get('command', '?')})")
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        out["traffic"] = (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+        out["traffic_if_fetch_doubled"] = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    if "SQ_ACTIVE_INST_VALU" in vals and "GRBM_GUI_ACTIVE" in vals:
+        # executed-work utilisation: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), per k_update launch
+        out["valu_busy"] = round(vals["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * vals["GRBM_GUI_ACTIVE"] / 8.0), 4)
     return out
 
 
@@ -394,8 +405,11 @@ def secondary(pm, engine, dev_index, cams, imgs_f32, gts, prm, args):
 # ---------------------------------------------------------------------------------------------------------------------
 # cfg 4
 # ---------------------------------------------------------------------------------------------------------------------
-def run_cfg4(args, pm, engine, dist, rank, world, dev_index, barrier):
+def run_cfg4(args, pm, engine, dist, rank, world, dev_index, barrier, steps=None, warmup=None):
+    """configs[4]; every rank calls it, rank 0 gets the result line (a dict), the others None"""
     import torch
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     sched = importlib.import_module("mp-mvs_amd.schedule")
     w4, h4 = (int(v) for v in args.cfg4_size.lower().split("x"))
     g = args.cfg4_grid
@@ -413,11 +427,11 @@ def run_cfg4(args, pm, engine, dist, rank, world, dev_index, barrier):
     s.fetch_results = not device_tensors
     s.timing = []
     barrier()
-    for i in range(args.warmup):
+    for i in range(warmup):
         s.run(seed=999 + i)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         s.run(seed=12345 + i)
     barrier()
     dt = time.perf_counter() - t0
@@ -431,15 +445,91 @@ def run_cfg4(args, pm, engine, dist, rank, world, dev_index, barrier):
         n = g * g
         passes = s.timing[-3:]
         out = {"metric": f"Mpix/s depth+normal (shipped schedule, {w4}x{h4}, 8 src views, {n} Problems sharded over the GPUs)",
-               "value": round(n * w4 * h4 * args.steps / dt / 1e6, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+               "value": round(n * w4 * h4 * steps / dt / 1e6, 3), "unit": "Mpix/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+               "ms_per_step": round(dt / steps * 1e3, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic, seeded height-field scene, images rounded to 8 bits",
                "config": {"workload": f"configs[4]: {n} reference-image Problems ({g}x{g} camera grid, 8 nearest neighbours as sources) sharded round-robin "
                                       f"over {world} rank(s); photometric 3 scales -> geometric + planar prior -> geometric; Jacobi barrier = one "
                                       f"all-gather of the depth maps per pass ({'RCCL all_gather_into_tensor on device buffers' if device_tensors and world > 1 else 'device buffers, single rank' if device_tensors else 'gloo, host staging (rehearsal)'})",
                           "width": w4, "height": h4, "problems": n, "src_views": 8, "host_threads_per_rank": args.workers},
                "passes_last_step": passes, "within_1pct_of_gt_rank0_mean": round(float(np.mean(acc)), 4)}
-        print(json.dumps(out), flush=True)
+        return out
+    return None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` without torch.distributed.run
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Parent of a self-launched multi-rank run.  Must not have touched the GPU (it has imported neither torch nor the HIP
+    library): starts n fresh children of this script, one per rank, waits for them, forwards rank 0's stdout (the JSON line)
+    and returns the exit code -- non-zero if any rank failed, in which case the others are terminated (by PID)."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, len(os.sched_getaffinity(0)) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+    import threading
+    lines = []
+
+    def pump():
+        for line in procs[0].stdout:
+            lines.append(line)
+            sys.stdout.write(line)
+            sys.stdout.flush()
+
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py launcher: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for q in pending:
+                    procs[q].terminate()
+        if pending:
+            time.sleep(0.05)
+    th.join(timeout=10)
+    if rc == 0 and not any(l.lstrip().startswith("{") for l in lines):
+        print("bench.py launcher: rank 0 printed no JSON line", file=sys.stderr, flush=True)
+        rc = 1
+    return rc
+
+
+def launch_check(args):
+    """--launch-check: the rank-side plumbing of a self-launched run without any GPU work (CPU test of the launcher): gloo
+    rendezvous from the environment the launcher set, a max-reduce over the ranks, one JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    if args.launch_check_fail_rank == rank:
+        time.sleep(0.5)
+        raise SystemExit(3)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "max_rank_plus_1": float(t.item()), "local_rank": int(os.environ["LOCAL_RANK"]),
+                          "master": os.environ["MASTER_ADDR"] + ":" + os.environ["MASTER_PORT"]}), flush=True)
+    dist.destroy_process_group()
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -459,11 +549,23 @@ def main():
     ap.add_argument("--cfg4-size", default="1600x1200")
     ap.add_argument("--cfg4-grid", type=int, default=8)
     ap.add_argument("--workers", type=int, default=6, help="cfg4: host threads per rank driving its Problems (measured on one MI355X, 64 Problems: 1 / 3 / 6 / 10 threads 14.6 / 10.7 / 9.4 / 9.7 s)")
+    ap.add_argument("--size", default=None, help="WxH of the cfg-1 Problem instead of 1600x1200 (tests of the multi-rank plumbing; the line says so)")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--child-seed", type=int, default=12345, help=argparse.SUPPRESS)
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--launch-check-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    global W, H
+    if args.size:
+        W, H = (int(v) for v in args.size.lower().split("x"))
     if args.cpu_baseline_child:
         cpu_baseline_child(args.cpu_baseline_child, args.child_seed, not args.float_images)
+        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly: become the launcher (nothing below this line runs in this process, which never touches the GPU)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.launch_check:
+        launch_check(args)
         return
     if args.steps is None:
         args.steps = 5 if args.workload == "cfg1" else 1
@@ -475,8 +577,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start it plainly (python bench.py --gpus N launches its own ranks) or with "
+                         f"torch.distributed.run --nproc-per-node {args.gpus}")
     dist = None
     dev_index = 0 if args.share_device else local_rank
     torch.cuda.set_device(dev_index)
@@ -496,7 +598,9 @@ def main():
         torch.cuda.synchronize()
 
     if args.workload == "cfg4":
-        run_cfg4(args, pm, engine, dist, rank, world, dev_index, barrier)
+        out = run_cfg4(args, pm, engine, dist, rank, world, dev_index, barrier)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -540,13 +644,28 @@ def main():
     # the two other readings of the metric (untimed by the driver): kernels only, and with the image upload
     barrier()
     dt_res, _, _, _ = timed_runs(pm, ctx, prm, seed, args.steps)
+    # SURVEY 8(d)'s wording of the metric ("uploads/downloads included"): image upload + Run() + D2H per step, on the same
+    # number of steps and between the same barriers as `value`
+    barrier()
     t0 = time.perf_counter()
-    n_h2d = min(3, args.steps)
-    for i in range(n_h2d):
+    for i in range(args.steps):
         ctx.set_views(cams, imgs)
-        ctx.run(prm, seed + i)
-        ctx.get_into(*bufs)
+        ctx.run_into(prm, seed + i, *bufs)
+    barrier()
     dt_h2d = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt_res, dt_h2d], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_res, dt_h2d = (float(v) for v in t.tolist())
+
+    # configs[4] in the same invocation when there is more than one rank: the only workload whose passes exchange depth maps
+    # (one all-gather per pass), so that one driver command yields the weak-scaling line AND an execution of the collective
+    cfg4_line = None
+    if world > 1 and not args.no_secondary:
+        del ctx
+        cfg4_line = run_cfg4(args, pm, engine, dist, rank, world, dev_index, barrier, steps=1, warmup=0)
+        ctx = engine.create(dev_index)
+        ctx.set_views(cams, imgs)
 
     if rank == 0:
         mpix = world * W * H * args.steps / dt / 1e6
@@ -554,8 +673,9 @@ def main():
         flops_per_launch, tflops = roofline_of(upd_avg_ms, W, H, V)
         hbm_bytes_per_launch = W * H * (4 * (V + 1) + 36)      # SURVEY.md 8d COMPULSORY_HBM_BYTES / L
         gbps = hbm_bytes_per_launch / (upd_avg_ms * 1e-3) / 1e9
+        prof = profile_counters(upd_avg_ms)
         out = {
-            "metric": "Mpix/s depth+normal (fixed iters, 1600x1200, 8 src views)",
+            "metric": f"Mpix/s depth+normal (fixed iters, {W}x{H}, 8 src views)",
             "value": round(mpix, 3),
             "unit": "Mpix/s",
             "n_gpus": world,
@@ -567,20 +687,22 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic, seeded height-field scene; images " + ("rounded to 8 bits like the reference's imread input" if quantize else "non-integer fp32") + f"; resident texture format {ctx.texture_format()}",
-            "config": {"workload": "configs[1]: 1 ref + 8 src views, 1600x1200, single-scale, photometric only, 3 red/black iterations, one Problem per GPU per step; "
+            "config": {"workload": ("" if (W, H) == (1600, 1200) else "NOT the BASELINE size (--size): ") + f"configs[1]: 1 ref + 8 src views, {W}x{H}, single-scale, photometric only, 3 red/black iterations, one Problem per GPU per step; "
                                    "a step = Run() incl. its device-to-host copies of planes + costs; the 9 images are resident in HBM when the timed region "
                                    "starts (bench contract), i.e. the image upload (H2D) is EXCLUDED from `value` -- SURVEY 8(d)'s wording of the metric, "
-                                   "upload + Run() + D2H per step, is `with_h2d_value` in this line",
+                                   "upload + Run() + D2H per step, is `value_survey_8d` in this line",
                        "width": W, "height": H, "src_views": V, "max_scale": 0, "iterations": ITERS},
             "comparable_across_rounds": "`value` (Run() + D2H) is the headline of rounds 2 and 3; `resident_value` (kernels only) was round 1's",
             "resident_value": round(world * W * H * args.steps / dt_res / 1e6, 3),
-            "with_h2d_value": round(W * H * n_h2d / dt_h2d / 1e6, 3),
+            "value_survey_8d": round(world * W * H * args.steps / dt_h2d / 1e6, 3),
+            "value_survey_8d_is": "SURVEY 8(d)'s wording of the metric: image upload (host 8-bit conversion, H2D, texture packing) + Run() + D2H per step, "
+                                  f"{args.steps} steps between the same barriers as `value`; `value` itself keeps the inputs resident (bench contract)",
             "roofline": {
                 "kernel": "k_update<photometric> (BlackPixelUpdate/RedPixelUpdate)",
                 "bound": "valu_fp32",
                 "frac_is": "algorithmic-equivalent rate (SURVEY 8d's nominal flop / measured time / peak), NOT executed-VALU utilisation: see `note` and "
                            "`valu_busy_from_profile`",
-                "valu_busy_from_profile": profile_valu_busy(),
+                "valu_busy_from_profile": prof["valu_busy"],
                 "achieved": round(tflops, 3),
                 "peak": PEAK_VALU_TFLOPS,
                 "unit": "TFLOP/s",
@@ -588,9 +710,10 @@ def main():
                 "note": "achieved = SURVEY 8d's ALGORITHMIC flop per launch (14 hypotheses x 8 views x 2144 flop per pixel of one colour) / measured launch time; the "
                         "kernel executes roughly half of that (bilateral weights and reference moments once per pixel, homography as 9 fmas, one reciprocal per six taps, "
                         "zero-weight views skipped): it is an algorithmic-equivalent rate, not the VALU utilisation (that is in profiles/: SQ_ACTIVE_INST_VALU)",
-                "traffic": (measured_traffic_bytes() or (None, None, None))[0],
-                "traffic_if_fetch_doubled": (measured_traffic_bytes() or (None, None, None))[1],
-                "traffic_source": (measured_traffic_bytes() or (None, None, None))[2],
+                "traffic": prof["traffic"],
+                "traffic_if_fetch_doubled": prof["traffic_if_fetch_doubled"],
+                "traffic_source": prof["source"],
+                "traffic_null_reason": prof["reason"],
                 "avg_launch_ms": round(upd_avg_ms, 4),
                 "launches_timed": upd_n,
                 "algorithmic_flop_per_launch": flops_per_launch,
@@ -608,6 +731,8 @@ def main():
             out["secondary"] = secondary(pm, engine, dev_index, cams, imgs_f32, gts, prm, args)
             ctx = engine.create(dev_index)
             ctx.set_views(cams, imgs)
+        if cfg4_line is not None:
+            out.setdefault("secondary", {})["cfg4"] = cfg4_line
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pm, ctx, cams, imgs, prm, seed, quantize)
         print(json.dumps(out), flush=True)

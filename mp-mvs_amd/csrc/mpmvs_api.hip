@@ -818,6 +818,27 @@ static void fill_spatial_terms(LaunchArgs& a, int scale) {
         }
 }
 
+// the canonical exp of pm_device.hpp (d_exp) on the host, for arguments <= 0: the same fma sequence, the same bits
+static float host_exp_canonical(float x) {
+    if (x < -80.0f) return 0.0f;
+    const float n = std::rint(x * 1.44269504088896341f);
+    float r = std::fma(n, -0.693359375f, x);
+    r = std::fma(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = std::fma(p, r, 1.3981999507e-3f);
+    p = std::fma(p, r, 8.3334519073e-3f);
+    p = std::fma(p, r, 4.1665795894e-2f);
+    p = std::fma(p, r, 1.6666665459e-1f);
+    p = std::fma(p, r, 5.0000001201e-1f);
+    const float y = std::fma(p, r * r, r) + 1.0f;
+    uint32_t bits;
+    memcpy(&bits, &y, 4);
+    bits += (uint32_t)(int)n << 23;
+    float out;
+    memcpy(&out, &bits, 4);
+    return out;
+}
+
 static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int kind, int iter, int scale, uint32_t launch) {
     if (scale < 0 || scale > 2) return fail(c, -3, "scale must be 0..2");
     if ((kind == MPMVS_KIND_BLACK || kind == MPMVS_KIND_RED) && scale != 0 && (p->geom_consistency || p->planar_prior))
@@ -835,6 +856,8 @@ static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int 
     a.two_ss = (2.0f * p->sigma_spatial) * p->sigma_spatial;
     a.two_sc = (2.0f * p->sigma_color) * p->sigma_color;
     fill_spatial_terms(a, scale);
+    // ref .cu:832: double product, one rounding to float
+    a.cost_threshold = (float)(0.8 * (double)host_exp_canonical((float)(iter * iter) / (-90.0f)));
     a.init_random = (!p->geom_consistency && !p->planar_prior) ? 1 : 0;
     a.use_prior = p->planar_prior ? 1 : 0;
 

@@ -38,6 +38,9 @@ struct LaunchArgs {
     // -sqrt(dx^2 + dy^2) / two_ss of the 36 window taps [column][row] at this launch's scale: the same for every pixel, so the
     // host computes it once per launch (the same fp32 square root and division the kernel used to do 36 times per pixel)
     float spatial[36];
+    // view-selection threshold of this iteration, ref .cu:832: `0.8 * expf(iter * iter / -90.0f)` multiplies in DOUBLE (0.8 is a
+    // double literal) and rounds once to float; it depends on the iteration only, so the host forms it per launch
+    float cost_threshold;
     int init_random;       // InitializeScore branch A (ref .cu:549)
     int use_prior;         // params.planar_prior
 };
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
     // every entry is zeroed as in ref .cu:821: the refinement's geometric term
     // reads view_w[candidate 0..4], beyond V when V < 5 (ref .cu:689)
     for (int v = 0; v < MAXV; ++v) view_w[v] = 0.0f;
-    const float thr = 0.8f * d_exp((float)(a.iter * a.iter) / (-90.0f));
+    const float thr = a.cost_threshold;  // ref .cu:832, formed on the host (LaunchArgs)
 
     // the pixel's current plane is read where it is needed (phase B) instead of being carried through phase A
     const float depth_sigma = (a.depth_max - a.depth_min) / 64.0f;

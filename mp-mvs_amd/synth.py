@@ -3,6 +3,7 @@ by a grid of pinhole cameras, rendered by per-pixel ray / height-field
 intersection.  No files, no OpenCV.  Used by bench.py and the tests; images are
 fp32 in [0, 255] like the reference's (reference src/PatchMatch.cpp:877-882).
 """
+import os
 from dataclasses import dataclass, field
 from typing import List
 
@@ -73,10 +74,10 @@ def _small_rotation(rng, max_deg):
     return Rz @ Rx @ Ry
 
 
-def render_view(width, height, K, R, Cc, seed, fs):
-    u, v = np.meshgrid(np.arange(width, dtype=np.float64), np.arange(height, dtype=np.float64))
+def _render_rows(width, y0, y1, K, R, Cc, seed, fs):
+    u, v = np.meshgrid(np.arange(width, dtype=np.float64), np.arange(y0, y1, dtype=np.float64))
     rc = np.stack([(u - K[0, 2]) / K[0, 0], (v - K[1, 2]) / K[1, 1], np.ones_like(u)], -1)
-    rw = rc @ R  # R^T applied to each ray (row vectors)
+    rw = rc @ R  # R^T applied to each ray (row vectors); a stack of per-row products, so a band gives the bits of the whole
     d = np.full(u.shape, 5.0)
     for _ in range(24):
         X = Cc[0] + d * rw[..., 0]
@@ -86,6 +87,19 @@ def render_view(width, height, K, R, Cc, seed, fs):
     Y = Cc[1] + d * rw[..., 1]
     img = albedo(X, Y, seed, fs)
     return img.astype(np.float32), d.astype(np.float32)
+
+
+def render_view(width, height, K, R, Cc, seed, fs):
+    # every pixel is independent: large images are rendered in row bands on a few threads (numpy releases the GIL inside its
+    # loops); the pixels are the same bits as in one piece
+    bands = min(8, len(os.sched_getaffinity(0)), height // 64)
+    if width * height < 400 * 300 or bands < 2:
+        return _render_rows(width, 0, height, K, R, Cc, seed, fs)
+    from concurrent.futures import ThreadPoolExecutor
+    cuts = [height * i // bands for i in range(bands + 1)]
+    with ThreadPoolExecutor(max_workers=bands) as pool:
+        parts = list(pool.map(lambda i: _render_rows(width, cuts[i], cuts[i + 1], K, R, Cc, seed, fs), range(bands)))
+    return np.concatenate([p[0] for p in parts], 0), np.concatenate([p[1] for p in parts], 0)
 
 
 def make_view(width, height, Cc, R, Kv, seed, depth_min, depth_max, quantize):

@@ -752,7 +752,7 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
                 for (int v = 0; v < V; ++v) vprior[v] += ((s >> v) & 1u) ? 0.9f : 0.1f;
             }
         float probs[kMaxViews];
-        const float thr = 0.8f * det_exp((float)(iter * iter) / (-90.0f));
+        const float thr = (float)(0.8 * (double)det_exp((float)(iter * iter) / (-90.0f)));  // ref .cu:832: the product is formed in double
         for (int v = 0; v < V; ++v) {
             float count = 0.0f, tmpw = 0.0f;
             int count_false = 0;

@@ -292,3 +292,29 @@ def test_folder_jacobi_workers_equal_the_scheduler(pm, engine, tmp_path):
     for i in range(6):
         planes, costs, _ = res[i]
         assert np.array_equal(out[3][i][0], planes[..., 3]) and np.array_equal(out[3][i][1], planes[..., :3]) and np.array_equal(out[3][i][2], costs), f"image {i}"
+
+
+def test_bench_self_launched_two_ranks_share_the_gpu():
+    """`python bench.py --gpus 2` started plainly: the launcher (which never touches the GPU) starts two fresh ranks; here both
+    use GPU 0 over gloo (a 1-GPU box cannot run RCCL between two ranks).  One JSON line: the cfg-1 weak-scaling figures and,
+    in the same invocation, configs[4] with its per-pass exchange (`secondary.cfg4`)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device", "--size", "320x240",
+                        "--cfg4-size", "160x120", "--cfg4-grid", "3", "--steps", "2", "--warmup", "1", "--workers", "2"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["width"] == 320 and "NOT the BASELINE size" in out["config"]["workload"]
+    assert out["value_survey_8d"] > 0 and out["within_1pct_of_gt"] > 0.8
+    c4 = out["secondary"]["cfg4"]
+    assert c4["n_gpus"] == 2 and c4["scaling"] == "strong" and c4["config"]["problems"] == 9
+    assert [p["pass"] for p in c4["passes_last_step"]] == ["photometric", "geometric + planar prior", "geometric"]
+    assert all(p["exchange_ms"] >= 0 for p in c4["passes_last_step"]) and c4["within_1pct_of_gt_rank0_mean"] > 0.6   # 160x120 views: coarser than the cfg-1 check above

@@ -69,3 +69,41 @@ def test_ranks_equal_one_rank(tmp_path, world, kw):
     sc, _ = pm.synth.make_grid_scene(W, H, NX, NY, spacing=0.5, rot_deg=1.0)
     gt = sc.views[0].gt_depth
     assert (np.abs(ref[0][0][..., 3] - gt) / gt < 0.1).mean() > 0.6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bench.py started plainly with --gpus N > 1 launches its own ranks (no torch.distributed.run, no exec after GPU init)
+# ---------------------------------------------------------------------------------------------------------------------
+def _bench_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    return env
+
+
+def test_bench_self_launch_two_ranks():
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=_bench_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["max_rank_plus_1"] == 2.0 and out["local_rank"] == 0 and out["master"].startswith("127.0.0.1:")
+
+
+def test_bench_self_launch_propagates_a_failed_rank():
+    import subprocess
+    # rank 1 dies before the collective: rank 0 would wait in it forever; the launcher must stop it and report failure
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check", "--launch-check-fail-rank", "1"],
+                       env=_bench_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "rank 1 exited with code 3" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_rank_count_mismatch_is_refused():
+    import subprocess
+    env = dict(_bench_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

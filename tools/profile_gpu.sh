@@ -8,10 +8,13 @@
 set -o pipefail
 TAG=${1:-r1}
 shift
-if [ $# -eq 0 ]; then set -- bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary; fi
+# default: the command whose line the driver records, minus the untimed extras -- so that the trace average of k_update is
+# comparable with the HIP-event average of the plain run (bench.py quotes the counters only if the two agree within 3 %)
+if [ $# -eq 0 ]; then set -- bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary; fi
 cd ${GRAFT_REPO_ROOT:?}
 export OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
+echo "python3 $*" > $OUT/command.txt
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:?}
 python3 "$@" > $OUT/plain.json 2>/dev/null   # also fills the scene cache
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 "$@" > $OUT/traced.json 2> $OUT/trace.err

@@ -9,6 +9,18 @@ from collections import defaultdict
 
 out = sys.argv[1]
 
+# header: which build and which command these numbers belong to (bench.py only quotes a profile whose hash equals the tree's)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+try:
+    import bench
+    print(f"# kernel_sources_sha256: {bench.kernel_sources_sha256()}")
+except Exception as e:  # noqa: BLE001
+    print(f"# kernel_sources_sha256: unavailable ({e})")
+for key, path in (("command", os.path.join(out, "command.txt")), ("git_head", os.path.join(ROOT, "build", "git_head.txt"))):
+    if os.path.exists(path):
+        print(f"# {key}: {open(path).read().strip()}")
+
 
 def short(name):
     for key in ("k_update", "k_init", "k_filter", "k_depth_normal", "k_pad", "k_export", "k_eval", "k_prior_raster", "k_prior"):
