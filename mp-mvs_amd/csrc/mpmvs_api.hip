@@ -245,6 +245,32 @@ static void cam_to_dev(const mpmvs_camera& s, CamDev& d) {
     std::memcpy(d.C, s.C, sizeof(d.C));
 }
 
+// Geometric consistency (ref .cu:582-640) as one projective map per direction: a pixel (x, y) of camera `a` at
+// depth z lands in camera `b` at  ~  z * G (x, y, 1)^T + g  with
+//   G = K_b (R_b R_a^T) Kinv'_a,   g = K_b (R_b C_a + t_b)
+// where Kinv'_a = [1/fx 0 -cx/fx; 0 1/fy -cy/fy; 0 0 1] is what BackProjectPoint2W applies (ref .cu:587-589: no skew), R_a^T and
+// C_a what it transforms with (:595-600), and R_b, t_b and the FULL K_b what ProjectPoint uses (:608-614).  Double, this fixed
+// order, one rounding to fp32; the oracle evaluates the same expressions.
+static void geom_maps(const mpmvs_camera& a, const mpmvs_camera& b, float G[9], float g[3]) {
+    const double fx = a.K[0], fy = a.K[4], cx = a.K[2], cy = a.K[5];
+    double Rba[9], M[9], tb[3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            Rba[i * 3 + j] = ((double)b.R[i * 3] * (double)a.R[j * 3] + (double)b.R[i * 3 + 1] * (double)a.R[j * 3 + 1]) +
+                             (double)b.R[i * 3 + 2] * (double)a.R[j * 3 + 2];
+    for (int i = 0; i < 3; ++i) {
+        M[i * 3 + 0] = Rba[i * 3 + 0] / fx;
+        M[i * 3 + 1] = Rba[i * 3 + 1] / fy;
+        M[i * 3 + 2] = (Rba[i * 3 + 2] - (Rba[i * 3 + 0] * cx) / fx) - (Rba[i * 3 + 1] * cy) / fy;
+        tb[i] = (((double)b.R[i * 3] * (double)a.C[0] + (double)b.R[i * 3 + 1] * (double)a.C[1]) + (double)b.R[i * 3 + 2] * (double)a.C[2]) + (double)b.t[i];
+    }
+    for (int i = 0; i < 3; ++i) {
+        const double k0 = b.K[i * 3], k1 = b.K[i * 3 + 1], k2 = b.K[i * 3 + 2];
+        for (int j = 0; j < 3; ++j) G[i * 3 + j] = (float)((k0 * M[0 + j] + k1 * M[3 + j]) + k2 * M[6 + j]);
+        g[i] = (float)((k0 * tb[0] + k1 * tb[1]) + k2 * tb[2]);
+    }
+}
+
 // per-view constants of H = A - b m^T, evaluated in double in the fixed order
 // of DESIGN.md section 3.3 and rounded once to fp32
 static void precompute_views(mpmvs_ctx* c) {
@@ -291,7 +317,8 @@ static void precompute_views(mpmvs_ctx* c) {
         o.hf = (float)s.height;
         o.wm1 = (float)(s.width - 1);
         o.hm1 = (float)(s.height - 1);
-        cam_to_dev(s, o.cam);
+        geom_maps(r, s, o.Gf, o.gf);   // reference pixel at depth z -> source pixel
+        geom_maps(s, r, o.Gb, o.gb);   // source pixel at depth d -> reference pixel
     }
 }
 

@@ -43,7 +43,10 @@ struct ViewDev {
     const float* depth;  // dense source depth map (geometric consistency) or null
     int dw, dh;
     float dwm1, dhm1;
-    CamDev cam;
+    // geometric consistency (ref .cu:582-640) as two composed projective maps, evaluated on the host in double and rounded
+    // once: reference pixel (x, y) at depth z -> source pixel  ~  z * Gf (x, y, 1)^T + gf,
+    // source pixel (u, v) at depth d -> reference pixel  ~  d * Gb (u, v, 1)^T + gb
+    float Gf[9], gf[3], Gb[9], gb[3];
 };
 
 struct ProblemDev {
@@ -734,6 +737,7 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, float
 // ---------------------------------------------------------------------------
 // geometric consistency (ref .cu:582-640)
 // ---------------------------------------------------------------------------
+// BackProjectPoint2W / ProjectPoint in the reference's own operation order (ref .cu:582-615): used by depth-map fusion (pm_fusion.hpp)
 PM_DEV void backproject(const CamDev& cam, float x, float y, float depth, float& o0, float& o1, float& o2) {
     const float X0 = (depth * (x - cam.K[2])) / cam.K[0];
     const float X1 = (depth * (y - cam.K[5])) / cam.K[4];
@@ -753,49 +757,58 @@ PM_DEV void project(const CamDev& cam, float p0, float p1, float p2, float& u, f
     u = ((cam.K[0] * t0 + cam.K[1] * t1) + cam.K[2] * t2) / d;
     v = ((cam.K[3] * t0 + cam.K[4] * t1) + cam.K[5] * t2) / d;
 }
-// ComputeGeomConsistencyCost (ref .cu:617-640) in two halves: the world point of pixel (px, py) on the hypothesis plane does
-// not depend on the source view (ref :621-624 recomputes it per view: 3 of the 9 divisions of a check), the reprojection does.
-struct GeomPoint {
-    float w0, w1, w2;
+// ComputeGeomConsistencyCost: forward-project the pixel at the hypothesis' depth into the source view, read the source depth
+// there (nearest texel, clamp), back-project and re-project into the reference view, cost = min(3, reprojection distance).
+// The reference walks through world coordinates with 9 divisions per check (BackProjectPoint2W, ProjectPoint twice each way);
+// here each direction is ONE projective map with host-composed constants (ViewDev::Gf/gf/Gb/gb): 9 + 9 fmas, two shared
+// reciprocals, no division -- ~60 instructions per check instead of ~290 (round 4; DESIGN.md 3.8 measures the distance of this
+// canonical form from the literal formulas).  The depth of the hypothesis at the pixel is view independent: computed once per
+// hypothesis by the caller (depth_from_plane).
+// The check in two halves, so that callers can put other work (or the first halves of other checks) between the depth gather
+// and its use: issue() projects forward and starts the load, finish() projects back.  A check issued and finished back to back
+// exposes the full latency of its gather (one scattered 4-byte load): 86 of them per pixel and iteration were 10 % of a wave's
+// lifetime.
+struct GeomCheck {
+    float su, sv, sd;
+    PM_DEV void issue(const ViewDev& vw, float z, int px, int py) {
+        const float fx = (float)px, fy = (float)py;
+        const float q0 = __builtin_fmaf(vw.Gf[1], fy, __builtin_fmaf(vw.Gf[0], fx, vw.Gf[2]));
+        const float q1 = __builtin_fmaf(vw.Gf[4], fy, __builtin_fmaf(vw.Gf[3], fx, vw.Gf[5]));
+        const float q2 = __builtin_fmaf(vw.Gf[7], fy, __builtin_fmaf(vw.Gf[6], fx, vw.Gf[8]));
+        const float h0 = __builtin_fmaf(z, q0, vw.gf[0]);
+        const float h1 = __builtin_fmaf(z, q1, vw.gf[1]);
+        const float h2 = __builtin_fmaf(z, q2, vw.gf[2]);
+        const float rh = d_rcp(h2);
+        su = h0 * rh;
+        sv = h1 * rh;
+        float qx = (su >= 0.0f) ? su : 0.0f;  // NaN -> 0
+        qx = (qx <= vw.dwm1) ? qx : vw.dwm1;
+        float qy = (sv >= 0.0f) ? sv : 0.0f;
+        qy = (qy <= vw.dhm1) ? qy : vw.dhm1;
+        sd = vw.depth[(long)(int)qy * vw.dw + (int)qx];  // nearest, ref .cu:626
+    }
+    PM_DEV float finish(const ViewDev& vw, int px, int py) const {
+        if (sd == 0.0f) return 3.0f;
+        const float fx = (float)px, fy = (float)py;
+        const float p0 = __builtin_fmaf(vw.Gb[1], sv, __builtin_fmaf(vw.Gb[0], su, vw.Gb[2]));
+        const float p1 = __builtin_fmaf(vw.Gb[4], sv, __builtin_fmaf(vw.Gb[3], su, vw.Gb[5]));
+        const float p2 = __builtin_fmaf(vw.Gb[7], sv, __builtin_fmaf(vw.Gb[6], su, vw.Gb[8]));
+        const float k0 = __builtin_fmaf(sd, p0, vw.gb[0]);
+        const float k1 = __builtin_fmaf(sd, p1, vw.gb[1]);
+        const float k2 = __builtin_fmaf(sd, p2, vw.gb[2]);
+        const float rk = d_rcp(k2);
+        const float dc = fx - k0 * rk, dr = fy - k1 * rk;
+        const float e = __builtin_sqrtf(__builtin_fmaf(dr, dr, dc * dc));
+        return (e < 3.0f) ? e : 3.0f;  // NaN -> 3
+    }
 };
-PM_DEV GeomPoint geom_world_point(const ProblemDev& P, const float4 pl, int px, int py) {
-    const float depth = depth_from_plane(P, pl, px, py);
-    GeomPoint g;
-    backproject(P.cam, (float)px, (float)py, depth, g.w0, g.w1, g.w2);
-    return g;
-}
-PM_DEV float geom_cost_view_body(const ProblemDev& P, const ViewDev& vw, const GeomPoint g, int px, int py) {
-    float su, sv;
-    project(vw.cam, g.w0, g.w1, g.w2, su, sv);
-    float qx = (su >= 0.0f) ? su : 0.0f;
-    qx = (qx <= vw.dwm1) ? qx : vw.dwm1;
-    float qy = (sv >= 0.0f) ? sv : 0.0f;
-    qy = (qy <= vw.dhm1) ? qy : vw.dhm1;
-    const float sd = vw.depth[(long)(int)qy * vw.dw + (int)qx];  // nearest, ref .cu:626
-    if (sd == 0.0f) return 3.0f;
-    float s0, s1, s2;
-    backproject(vw.cam, su, sv, sd, s0, s1, s2);
-    float bu, bv;
-    project(P.cam, s0, s1, s2, bu, bv);
-    const float dc = (float)px - bu, dr = (float)py - bv;
-    const float e = __builtin_sqrtf(dc * dc + dr * dr);
-    return (e < 3.0f) ? e : 3.0f;
-}
-// CALL = true: a real function call instead of inlining.  The update kernel inlines the check three times next to the
-// unrolled NCC loop; with more than 8 views (bigger per-view arrays) that pushed the geometric variants into hundreds of
-// spilled registers (0.100 instead of 0.048 ns per evaluation at 20 views); at 8 views inlining is the faster form.
-__device__ __attribute__((noinline)) float geom_cost_view_call(const ProblemDev& P, const ViewDev& vw, const GeomPoint g, int px, int py) {
-    return geom_cost_view_body(P, vw, g, px, py);
-}
-template <bool CALL>
-PM_DEV float geom_cost_view(const ProblemDev& P, const ViewDev& vw, const GeomPoint g, int px, int py) {
-    if constexpr (CALL)
-        return geom_cost_view_call(P, vw, g, px, py);
-    else
-        return geom_cost_view_body(P, vw, g, px, py);
+PM_DEV float geom_cost_view_body(const ViewDev& vw, float z, int px, int py) {
+    GeomCheck g;
+    g.issue(vw, z, px, py);
+    return g.finish(vw, px, py);
 }
 PM_DEV float geom_cost(const ProblemDev& P, const ViewDev& vw, const float4 pl, int px, int py) {
-    return geom_cost_view_body(P, vw, geom_world_point(P, pl, px, py), px, py);
+    return geom_cost_view_body(vw, depth_from_plane(P, pl, px, py), px, py);
 }
 
 }  // namespace pm

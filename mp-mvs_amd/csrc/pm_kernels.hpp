@@ -244,7 +244,6 @@ PM_DEV float prior_term(float depth_diff, float angle_cos, float two_ds2, float 
 template <bool GEOM, bool PRIOR, int MAXV, bool U8, int SCALE>
 __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
     const ProblemDev& P = *Pp;
-    constexpr bool kGeomCall = MAXV > 8;  // see geom_cost_view
     // gathers of two window columns ahead (ncc_core): always with the 8-byte texels; with the 16-byte ones where the variant
     // still has the 24 registers of a third column (8 views; more views spill 4 .. 81 registers around the evaluations)
 #ifndef PM_F32_DEEP_WHEN
@@ -298,7 +297,14 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
         if (best < 3.402823466e+38f) flags |= (1u << k);
     }
 
+#ifdef PM_DBG_NOCOSTARR  // measurement builds only (results are wrong): the candidate cost matrix collapsed into one register --
+    // bounds what taking its 8 x V stores and loads out of private memory could give
+    float cost_arr[1];
+#define PM_CIDX(i) 0
+#else
     float cost_arr[8 * MAXV];
+#define PM_CIDX(i) (i)
+#endif
     int cnt[MAXV];       // good count | bad count << 8   (ref .cu:834-845)
     float tmpw[MAXV];
     float probs[MAXV];
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
                 c = ncc_cost<U8, SCALE, kDeep>(P.views[v], rw, x, y, m0, m1, m2);
             else
                 c = (slot == 0 && v == 0) ? 2.0f : 0.0f;  // `= {2.0f}` initialiser quirk, ref .cu:795
-            cost_arr[slot * MAXV + v] = c;
+            cost_arr[PM_CIDX(slot * MAXV + v)] = c;
             if (c < thr) {
                 tw += d_exp_inrange((c * c) / (-0.18f));  // c in [0, 2]: argument in [-22.3, 0]
                 cn += 1;
@@ -434,26 +440,46 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
         }
     // ---- weighted candidate costs (ref .cu:880-899)
     float fcv[8];
-    for (int i = 0; i < 8; ++i) {
-        const bool fl = (flags >> i) & 1u;
-        GeomPoint gp{0.f, 0.f, 0.f};
-        if (GEOM && fl) gp = geom_world_point(P, S.planes[pos[i]], x, y);
-        float fc = 0.0f;
+    if constexpr (GEOM) {
+        // VIEW by view, the geometric checks of the eight candidates of a view together: their forward halves first (eight
+        // depth gathers in flight), then their backward halves -- a check issued and finished on its own exposes the whole
+        // latency of its gather, 8 x V times per pixel.  For a fixed candidate the views are still added in ascending order.
+        float gz[8];  // depth of the candidate's plane at this pixel: shared by the checks of all views
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            fcv[i] = 0.0f;
+            gz[i] = ((flags >> i) & 1u) ? depth_from_plane(P, S.planes[pos[i]], x, y) : 0.0f;
+        }
         for (int v = 0; v < V; ++v) {
-            if (view_w[v] > 0.0f) {
-                if (GEOM) {
-                    if (fl)
-                        fc += view_w[v] * (cost_arr[i * MAXV + v] + 0.2f * geom_cost_view<kGeomCall>(P, P.views[v], gp, x, y));
-                    else
-                        fc += view_w[v] * (cost_arr[i * MAXV + v] + 0.1f * 3.0f);
-                } else {
-                    fc += view_w[v] * cost_arr[i * MAXV + v];
-                }
+            const float w = view_w[v];
+            if (!(w > 0.0f)) continue;
+            GeomCheck gc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if ((flags >> i) & 1u) gc[i].issue(P.views[v], gz[i], x, y);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float c = cost_arr[PM_CIDX(i * MAXV + v)];
+                if ((flags >> i) & 1u)
+                    fcv[i] += w * (c + 0.2f * gc[i].finish(P.views[v], x, y));
+                else
+                    fcv[i] += w * (c + 0.1f * 3.0f);
             }
         }
-        const float fci = fc / weight_norm;
-        final_costs[i] = fci;
-        fcv[i] = fci;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            fcv[i] = fcv[i] / weight_norm;
+            final_costs[i] = fcv[i];
+        }
+    } else {
+        for (int i = 0; i < 8; ++i) {
+            float fc = 0.0f;
+            for (int v = 0; v < V; ++v)
+                if (view_w[v] > 0.0f) fc += view_w[v] * cost_arr[PM_CIDX(i * MAXV + v)];
+            const float fci = fc / weight_norm;
+            final_costs[i] = fci;
+            fcv[i] = fci;
+        }
     }
     {
         float mc = fcv[0];
@@ -473,17 +499,19 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
         plane_now = pl;
         float m0, m1, m2;
         plane_to_m(P, pl, m0, m1, m2);
-        GeomPoint gp{0.f, 0.f, 0.f};
-        if (GEOM) gp = geom_world_point(P, pl, x, y);
+        float gz = 0.0f;
+        if (GEOM) gz = depth_from_plane(P, pl, x, y);
         float tc = 0.0f, tg = 0.0f;
         float w_next = view_w[0];  // one view ahead: hides the latency of private memory
         for (int v = 0; v < V; ++v) {
             const float w = w_next;
             w_next = view_w[v + 1 < MAXV ? v + 1 : v];
             if (!(w > 0.0f)) continue;
+            GeomCheck gc;
+            if (GEOM) gc.issue(P.views[v], gz, x, y);  // the depth gather travels behind the NCC evaluation
             const float c = ncc_cost<U8, SCALE, kDeep>(P.views[v], rw, x, y, m0, m1, m2);
             if (GEOM) {
-                const float gt = 0.2f * geom_cost_view<kGeomCall>(P, P.views[v], gp, x, y);
+                const float gt = 0.2f * gc.finish(P.views[v], x, y);
                 tc += w * (c + gt);
                 tg += w * gt;
             } else {
@@ -693,9 +721,11 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
                     const int ox = wave_x + 2 * (owner % kLanesPerRow) + ((oy + a.parity) & 1);
                     float m0, m1, m2;
                     plane_to_m(P, ipl, m0, m1, m2);
+                    GeomCheck gc;
+                    if (GEOM) gc.issue(P.views[v], depth_from_plane(P, ipl, ox, oy), ox, oy);
                     const float c = ncc_cost<U8, SCALE, kDeep>(P.views[v], orw, ox, oy, m0, m1, m2);
                     float gt = 0.0f;
-                    if (GEOM) gt = 0.2f * geom_cost_view<kGeomCall>(P, P.views[v], geom_world_point(P, ipl, ox, oy), ox, oy);
+                    if (GEOM) gt = 0.2f * gc.finish(P.views[v], ox, oy);
                     x_res[rank] = make_float2(c, gt);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -76,6 +76,21 @@ def eval_ncc_literal(handle, params, planes_cam, scale, quantize_fraction=False)
     return out
 
 
+def eval_geom_literal(handle, params, planes_cam):
+    """geometric-consistency cost through the reference's literal chain of world coordinates (9 divisions per check); the
+    canonical form (two composed projective maps, handle.eval_geom) is measured against it"""
+    import numpy as np
+    l, _ = lib()
+    l.orc_eval_geom_literal.restype = C.c_int
+    l.orc_eval_geom_literal.argtypes = [C.c_void_p, C.POINTER(_abi.PatchMatchParams), C.c_void_p, C.c_void_p]
+    p = np.ascontiguousarray(planes_cam, np.float32)
+    out = np.empty((params.num_images - 1, handle.H, handle.W), np.float32)
+    rc = l.orc_eval_geom_literal(handle._ctx, C.byref(params), p.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"orc_eval_geom_literal failed ({rc})")
+    return out
+
+
 def fuse(cams, estimate, depths, normals, colors, sources, use_dynamic=True, sequential_literal=False, sky=None, reference_order=False):
     """oracle fusion: mode 0 = the snapshot formulation (the GPU's default), mode 1 = the reference's literal sequential
     order with libm (measurement only), mode 2 (reference_order) = the sequential order in the canonical arithmetic = what

@@ -171,6 +171,36 @@ inline float det_acos(float x) {
     return 1.57079632679489661923f - det_asin_core(x);
 }
 
+// ---------------------------------------------------------------------------
+// Math of the MEASUREMENT modes (Ctx::literal_mode).  Mode 0 is the canonical arithmetic above -- what the
+// HIP kernels compute and every parity test compares.  The other modes exist to measure how far mode 0 is from the reference:
+//   1  the reference's formulas as written, IEEE operations in its operation order, libm expf / sinf / cosf / acosf;
+//   2  = 1 with CUDA's texture filter (8-bit interpolation fractions);
+//   3  a model of the reference BINARY, which is built with nvcc --use_fast_math (ref CMakeLists.txt:18): __expf =
+//      ex2.approx(x * log2 e), __sinf / __cosf (absolute error 2^-21.4), every division a multiplication by rcp.approx, fused
+//      multiply-adds where nvcc contracts, 8-bit texture fractions.  The approximate instructions are modelled by correctly
+//      rounded functions of the ROUNDED intermediate (their error bounds are 1-2 ulp; which ulp the hardware picks is not
+//      published): mode 3 is "a second build of the reference's formulas", the control that shows how many pixels the
+//      reference's own arithmetic variants flip against each other (tests/test_literal_gpu.py).
+// ---------------------------------------------------------------------------
+inline float m_div(int lm, float a, float b) { return lm == 3 ? a * (1.0f / b) : a / b; }
+inline float m_exp(int lm, float x) {
+    if (lm == 0) return det_exp(x);
+    if (lm == 3) return (float)exp2((double)(x * 1.44269504f));
+    return expf(x);
+}
+inline float m_sin(int lm, float a) {
+    if (lm == 0) return det_sin(a);
+    if (lm == 3) return rintf((float)sin((double)a) * 4194304.0f) / 4194304.0f;
+    return sinf(a);
+}
+inline float m_cos(int lm, float a) {
+    if (lm == 0) return det_cos(a);
+    if (lm == 3) return rintf((float)cos((double)a) * 4194304.0f) / 4194304.0f;
+    return cosf(a);
+}
+inline float m_acos(int lm, float x) { return lm == 0 ? det_acos(x) : acosf(x); }
+
 // Philox4x32-10 (Salmon et al. 2011), counter = (pixel, launch, block, tag).
 struct Rng {
     uint32_t key0, key1, pix, launch, k;
@@ -230,6 +260,9 @@ struct ViewConst {
     float A[9];
     float b[3];
     float wf, hf;  // (float)width, (float)height of the source
+    // geometric consistency as two composed projective maps: reference pixel at depth z -> source pixel
+    // ~ z * Gf (x, y, 1)^T + gf; source pixel at depth d -> reference pixel ~ d * Gb (u, v, 1)^T + gb
+    float Gf[9], gf[3], Gb[9], gb[3];
 };
 
 struct Ctx {
@@ -250,6 +283,29 @@ struct Ctx {
     int literal_mode = 0;  // 0 canonical NCC; 1 literal restatement; 2 literal + 8-bit texture fractions (measurement only)
     std::string err;
 };
+
+// G = K_b (R_b R_a^T) Kinv'_a, g = K_b (R_b C_a + t_b): a pixel of camera a at depth z seen in camera b (ref .cu:582-615:
+// BackProjectPoint2W applies Kinv' -- no skew --, R_a^T and C_a; ProjectPoint applies R_b, t_b and the full K_b).  Double, in
+// this fixed order, rounded once.
+void geom_maps(const Camera& a, const Camera& b, float G[9], float g[3]) {
+    const double fx = a.K[0], fy = a.K[4], cx = a.K[2], cy = a.K[5];
+    double Rba[9], M[9], tb[3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            Rba[i * 3 + j] = ((double)b.R[i * 3] * (double)a.R[j * 3] + (double)b.R[i * 3 + 1] * (double)a.R[j * 3 + 1]) +
+                             (double)b.R[i * 3 + 2] * (double)a.R[j * 3 + 2];
+    for (int i = 0; i < 3; ++i) {
+        M[i * 3 + 0] = Rba[i * 3 + 0] / fx;
+        M[i * 3 + 1] = Rba[i * 3 + 1] / fy;
+        M[i * 3 + 2] = (Rba[i * 3 + 2] - (Rba[i * 3 + 0] * cx) / fx) - (Rba[i * 3 + 1] * cy) / fy;
+        tb[i] = (((double)b.R[i * 3] * (double)a.C[0] + (double)b.R[i * 3 + 1] * (double)a.C[1]) + (double)b.R[i * 3 + 2] * (double)a.C[2]) + (double)b.t[i];
+    }
+    for (int i = 0; i < 3; ++i) {
+        const double k0 = b.K[i * 3], k1 = b.K[i * 3 + 1], k2 = b.K[i * 3 + 2];
+        for (int j = 0; j < 3; ++j) G[i * 3 + j] = (float)((k0 * M[0 + j] + k1 * M[3 + j]) + k2 * M[6 + j]);
+        g[i] = (float)((k0 * tb[0] + k1 * tb[1]) + k2 * tb[2]);
+    }
+}
 
 void precompute_views(Ctx& c) {
     const Camera& r = c.cams[0];
@@ -287,6 +343,8 @@ void precompute_views(Ctx& c) {
         o.b[2] = (float)(k8 * trel[2]);
         o.wf = (float)s.width;
         o.hf = (float)s.height;
+        geom_maps(r, s, o.Gf, o.gf);
+        geom_maps(s, r, o.Gb, o.gb);
     }
 }
 
@@ -294,21 +352,21 @@ void precompute_views(Ctx& c) {
 // Geometry helpers
 // ---------------------------------------------------------------------------
 // ref .cu:84-87
-inline float depth_from_plane(const Camera& cam, const F4& pl, int px, int py) {
-    const float den = ((float)px - cam.K[2]) * pl.x + ((cam.K[0] / cam.K[4]) * ((float)py - cam.K[5])) * pl.y + cam.K[0] * pl.z;
-    return (-pl.w * cam.K[0]) / den;
+inline float depth_from_plane(const Camera& cam, const F4& pl, int px, int py, int lm = 0) {
+    const float den = ((float)px - cam.K[2]) * pl.x + (m_div(lm, cam.K[0], cam.K[4]) * ((float)py - cam.K[5])) * pl.y + cam.K[0] * pl.z;
+    return m_div(lm, -pl.w * cam.K[0], den);
 }
 // ref .cu:163-176
-inline float plane_offset(const Camera& cam, int px, int py, float depth, const F4& n) {
-    const float X0 = (depth * ((float)px - cam.K[2])) / cam.K[0];
-    const float X1 = (depth * ((float)py - cam.K[5])) / cam.K[4];
+inline float plane_offset(const Camera& cam, int px, int py, float depth, const F4& n, int lm = 0) {
+    const float X0 = m_div(lm, depth * ((float)px - cam.K[2]), cam.K[0]);
+    const float X1 = m_div(lm, depth * ((float)py - cam.K[5]), cam.K[4]);
     const float X2 = depth;
     return -((n.x * X0 + n.y * X1) + n.z * X2);
 }
 // ref .cu:179-186
-inline void view_dir(const Camera& cam, int px, int py, float v[3]) {
-    v[0] = ((float)px - cam.K[2]) / cam.K[0];
-    v[1] = ((float)py - cam.K[5]) / cam.K[4];
+inline void view_dir(const Camera& cam, int px, int py, float v[3], int lm = 0) {
+    v[0] = m_div(lm, (float)px - cam.K[2], cam.K[0]);
+    v[1] = m_div(lm, (float)py - cam.K[5], cam.K[4]);
     v[2] = 1.0f;
 }
 // ref .cu:188-195 (rsqrtf -> 1/sqrt, both correctly rounded)
@@ -320,7 +378,7 @@ inline void normalize3(F4& n) {
     n.z *= inv;
 }
 // ref .cu:197-219
-inline F4 random_normal(const Camera& cam, int px, int py, Rng& g) {
+inline F4 random_normal(const Camera& cam, int px, int py, Rng& g, int lm = 0) {
     float q1, q2, s;
     do {
         q1 = 2.0f * rng_uniform(g) - 1.0f;
@@ -334,7 +392,7 @@ inline F4 random_normal(const Camera& cam, int px, int py, Rng& g) {
     n.z = 1.0f - 2.0f * s;
     n.w = 0.0f;
     float vd[3];
-    view_dir(cam, px, py, vd);
+    view_dir(cam, px, py, vd, lm);
     const float dp = (n.x * vd[0] + n.y * vd[1]) + n.z * vd[2];
     if (dp > 0.0f) {
         n.x = -n.x;
@@ -345,14 +403,14 @@ inline F4 random_normal(const Camera& cam, int px, int py, Rng& g) {
     return n;
 }
 // ref .cu:460-495
-inline F4 perturbed_normal(const Camera& cam, int px, int py, const F4& normal, Rng& g, float perturbation) {
+inline F4 perturbed_normal(const Camera& cam, int px, int py, const F4& normal, Rng& g, float perturbation, int lm = 0) {
     float vd[3];
-    view_dir(cam, px, py, vd);
+    view_dir(cam, px, py, vd, lm);
     const float a1 = (rng_uniform(g) - 0.5f) * perturbation;
     const float a2 = (rng_uniform(g) - 0.5f) * perturbation;
     const float a3 = (rng_uniform(g) - 0.5f) * perturbation;
-    const float s1 = det_sin(a1), s2 = det_sin(a2), s3 = det_sin(a3);
-    const float c1 = det_cos(a1), c2 = det_cos(a2), c3 = det_cos(a3);
+    const float s1 = m_sin(lm, a1), s2 = m_sin(lm, a2), s3 = m_sin(lm, a3);
+    const float c1 = m_cos(lm, a1), c2 = m_cos(lm, a2), c3 = m_cos(lm, a3);
     float R[9];
     R[0] = c2 * c3;
     R[1] = (c3 * s1) * s2 - c1 * s3;
@@ -563,7 +621,9 @@ inline void project(const Camera& cam, const float P[3], float& u, float& v) {
     u = ((cam.K[0] * t0 + cam.K[1] * t1) + cam.K[2] * t2) / d;
     v = ((cam.K[3] * t0 + cam.K[4] * t1) + cam.K[5] * t2) / d;
 }
-inline float geom_cost(const Ctx& c, int v /*0-based source*/, const F4& pl, int px, int py) {
+// the reference's own chain through world coordinates (ref .cu:617-640), IEEE operations in the reference's order: the LITERAL
+// form, used when Ctx::literal_mode != 0 and by the probe that measures the distance of the canonical form below from it
+inline float geom_cost_literal(const Ctx& c, int v /*0-based source*/, const F4& pl, int px, int py) {
     const Camera& rc = c.cams[0];
     const Camera& sc = c.cams[v + 1];
     const Image& dm = c.depths[v];
@@ -585,6 +645,35 @@ inline float geom_cost(const Ctx& c, int v /*0-based source*/, const F4& pl, int
     project(rc, Ps, bu, bv);
     const float dc = (float)px - bu, dr = (float)py - bv;
     const float e = sqrtf(dc * dc + dr * dr);
+    return (e < 3.0f) ? e : 3.0f;
+}
+// Canonical form: each direction is one projective map with host-composed constants, two shared reciprocals,
+// no division; what the HIP kernel computes (pm_device.hpp geom_cost_view_body), bit for bit.
+inline float geom_cost(const Ctx& c, int v /*0-based source*/, const F4& pl, int px, int py) {
+    if (c.literal_mode) return geom_cost_literal(c, v, pl, px, py);
+    const ViewConst& vc = c.vc[v];
+    const Image& dm = c.depths[v];
+    const float z = depth_from_plane(c.cams[0], pl, px, py);
+    const float fx = (float)px, fy = (float)py;
+    const float q0 = fmaf(vc.Gf[1], fy, fmaf(vc.Gf[0], fx, vc.Gf[2]));
+    const float q1 = fmaf(vc.Gf[4], fy, fmaf(vc.Gf[3], fx, vc.Gf[5]));
+    const float q2 = fmaf(vc.Gf[7], fy, fmaf(vc.Gf[6], fx, vc.Gf[8]));
+    const float h0 = fmaf(z, q0, vc.gf[0]), h1 = fmaf(z, q1, vc.gf[1]), h2 = fmaf(z, q2, vc.gf[2]);
+    const float rh = det_rcp(h2);
+    const float su = h0 * rh, sv = h1 * rh;
+    float qx = (su >= 0.0f) ? su : 0.0f;
+    qx = (qx <= (float)(dm.w - 1)) ? qx : (float)(dm.w - 1);
+    float qy = (sv >= 0.0f) ? sv : 0.0f;
+    qy = (qy <= (float)(dm.h - 1)) ? qy : (float)(dm.h - 1);
+    const float sd = dm.px[(size_t)(int)qy * dm.w + (int)qx];
+    if (sd == 0.0f) return 3.0f;
+    const float p0 = fmaf(vc.Gb[1], sv, fmaf(vc.Gb[0], su, vc.Gb[2]));
+    const float p1 = fmaf(vc.Gb[4], sv, fmaf(vc.Gb[3], su, vc.Gb[5]));
+    const float p2 = fmaf(vc.Gb[7], sv, fmaf(vc.Gb[6], su, vc.Gb[8]));
+    const float k0 = fmaf(sd, p0, vc.gb[0]), k1 = fmaf(sd, p1, vc.gb[1]), k2 = fmaf(sd, p2, vc.gb[2]);
+    const float rk = det_rcp(k2);
+    const float dc = fx - k0 * rk, dr = fy - k1 * rk;
+    const float e = sqrtf(fmaf(dr, dr, dc * dc));
     return (e < 3.0f) ? e : 3.0f;
 }
 
@@ -615,7 +704,7 @@ inline float initial_cost(const Ctx& c, const Params& prm, const RefWin& rw, int
         const float thr = sorted[top_k - 1];
         for (int v = 0; v < V; ++v)
             if (cv[v] <= thr) sel |= (1u << v);
-        return cost / (float)top_k;
+        return m_div(c.literal_mode, cost, (float)top_k);
     }
     return 2.0f;
 }
@@ -624,14 +713,15 @@ inline float initial_cost(const Ctx& c, const Params& prm, const RefWin& rw, int
 void init_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int scale, int px, int py) {
     const int idx = py * c.W + px;
     const Camera& cam = c.cams[0];
+    const int lm = c.literal_mode;  // 0: canonical arithmetic; 1-3: measurement modes (m_exp, m_div ...)
     Rng g = rng_make(seed, (uint32_t)idx, launch);
     RefWin rw;
     ref_window(c, prm, px, py, scale, rw);
     F4 pl;
     if (!prm.geom_consistency && !prm.planar_prior) {
-        pl = random_normal(cam, px, py, g);
+        pl = random_normal(cam, px, py, g, lm);
         const float depth = rng_uniform(g) * (prm.depth_max - prm.depth_min) + prm.depth_min;
-        pl.w = plane_offset(cam, px, py, depth, pl);
+        pl.w = plane_offset(cam, px, py, depth, pl, lm);
     } else if (prm.planar_prior && c.mask[idx] > 0 && c.costs[idx] >= 0.1f) {
         const float perturbation = 0.02f;
         const F4 pp = c.prior[idx];
@@ -639,14 +729,14 @@ void init_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int s
         const float dmin_p = (1.0f - 3.0f * perturbation) * dpert;
         const float dmax_p = (1.0f + 3.0f * perturbation) * dpert;
         dpert = rng_uniform(g) * (dmax_p - dmin_p) + dmin_p;
-        pl = perturbed_normal(cam, px, py, pp, g, 0.18849556f /* 3*0.02*pi */);
+        pl = perturbed_normal(cam, px, py, pp, g, 0.18849556f /* 3*0.02*pi */, lm);
         pl.w = dpert;
     } else {
         const F4 st = c.planes[idx];  // (world normal, depth) from the previous run
         pl.x = (cam.R[0] * st.x + cam.R[1] * st.y) + cam.R[2] * st.z;
         pl.y = (cam.R[3] * st.x + cam.R[4] * st.y) + cam.R[5] * st.z;
         pl.z = (cam.R[6] * st.x + cam.R[7] * st.y) + cam.R[8] * st.z;
-        pl.w = plane_offset(cam, px, py, st.w, pl);
+        pl.w = plane_offset(cam, px, py, st.w, pl, lm);
     }
     c.planes[idx] = pl;
     uint32_t sel;
@@ -669,9 +759,9 @@ static const int8_t kDirs[8][12][2] = {
     {{5, 0}, {7, 0}, {9, 0}, {11, 0}, {13, 0}, {15, 0}, {17, 0}, {19, 0}, {21, 0}, {23, 0}, {0, 0}, {0, 0}}};
 static const int kNumDirs[8] = {12, 12, 12, 12, 10, 10, 10, 10};
 
-inline float prior_term(float depth_diff, float angle_cos, float two_ds2, float two_as2) {
-    const float ad = det_acos(angle_cos);
-    return 0.5f + det_exp(-depth_diff * depth_diff / two_ds2) * det_exp(-ad * ad / two_as2);
+inline float prior_term(int lm, float depth_diff, float angle_cos, float two_ds2, float two_as2) {
+    const float ad = m_acos(lm, angle_cos);
+    return 0.5f + m_exp(lm, m_div(lm, -depth_diff * depth_diff, two_ds2)) * m_exp(lm, m_div(lm, -ad * ad, two_as2));
 }
 
 // Statistics hook for sizing kernel optimisations (tests/analysis/prune_stats.py): when set, every update_pixel records, per
@@ -692,6 +782,7 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
     const int V = prm.num_images - 1;
     const Camera& cam = c.cams[0];
     const bool geom = prm.geom_consistency, prior = prm.planar_prior;
+    const int lm = c.literal_mode;  // 0: canonical arithmetic; 1-3: measurement modes (m_exp, m_div ...)
     Rng g = rng_make(seed, (uint32_t)idx, launch);
     RefWin rw;
     ref_window(c, prm, px, py, scale, rw);
@@ -752,29 +843,29 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
                 for (int v = 0; v < V; ++v) vprior[v] += ((s >> v) & 1u) ? 0.9f : 0.1f;
             }
         float probs[kMaxViews];
-        const float thr = (float)(0.8 * (double)det_exp((float)(iter * iter) / (-90.0f)));  // ref .cu:832: the product is formed in double
+        const float thr = (float)(0.8 * (double)m_exp(lm, m_div(lm, (float)(iter * iter), -90.0f)));  // ref .cu:832: the product is formed in double
         for (int v = 0; v < V; ++v) {
             float count = 0.0f, tmpw = 0.0f;
             int count_false = 0;
             for (int j = 0; j < 8; ++j) {
                 const float cj = cost_arr[j][v];
                 if (cj < thr) {
-                    tmpw += det_exp((cj * cj) / (-0.18f));
+                    tmpw += m_exp(lm, m_div(lm, cj * cj, -0.18f));
                     count += 1.0f;
                 }
                 if (cj > 1.2f) count_false++;
             }
             if (count > 2.0f && count_false < 3)
-                probs[v] = (vprior[v] * tmpw) / count;
+                probs[v] = m_div(lm, vprior[v] * tmpw, count);
             else if (count_false < 3)
-                probs[v] = vprior[v] * det_exp((thr * thr) / (-0.32f));
+                probs[v] = vprior[v] * m_exp(lm, m_div(lm, thr * thr, -0.32f));
             else
                 probs[v] = 0.0f;
         }
         // ref .cu:42-56 (0 * inf = NaN when all probabilities vanish, quirk a-9 v)
         float psum = 0.0f;
         for (int v = 0; v < V; ++v) psum += probs[v];
-        const float inv = 1.0f / psum;
+        const float inv = m_div(lm, 1.0f, psum);
         float cum = 0.0f;
         for (int v = 0; v < V; ++v) {
             cum += probs[v] * inv;
@@ -817,7 +908,7 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
                 }
             }
         }
-        final_costs[i] = fc / weight_norm;
+        final_costs[i] = m_div(lm, fc, weight_norm);
     }
     int min_idx = 0;
     {
@@ -846,17 +937,17 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
             }
         }
     }
-    cost_now /= weight_norm;
+    cost_now = m_div(lm, cost_now, weight_norm);
     if (geom) {
-        geom_now /= weight_norm;
+        geom_now = m_div(lm, geom_now, weight_norm);
         c.geom[idx] = geom_now;
     }
     c.costs[idx] = cost_now;
-    float depth_now = depth_from_plane(cam, cur, px, py);
+    float depth_now = depth_from_plane(cam, cur, px, py, lm);
     float restricted_cost = 0.0f;
     F4 plane_now = cur;
 
-    const float depth_sigma = (prm.depth_max - prm.depth_min) / 64.0f;
+    const float depth_sigma = m_div(lm, prm.depth_max - prm.depth_min, 64.0f);
     const float two_ds2 = (2.0f * depth_sigma) * depth_sigma;
     const float angle_sigma = 0.08726646f;  // pi * 5/180
     const float two_as2 = (2.0f * angle_sigma) * angle_sigma;
@@ -865,16 +956,16 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
     // -- planar-prior assisted acceptance (ref .cu:924-978)
     if (prior && !geom) {
         const F4 pp = c.prior[idx];
-        const float depth_prior = depth_from_plane(cam, pp, px, py);
+        const float depth_prior = depth_from_plane(cam, pp, px, py, lm);
         if (c.mask[idx] > 0) {
             float rfc[8];
             for (int i = 0; i < 8; ++i) {
                 rfc[i] = 0.0f;
                 if (flag[i]) {
-                    const float di = depth_from_plane(cam, cand[i], px, py);
+                    const float di = depth_from_plane(cam, cand[i], px, py, lm);
                     const float ac = (pp.x * cand[i].x + pp.y * cand[i].y) + pp.z * cand[i].z;
-                    const float pr = prior_term(di - depth_prior, ac, two_ds2, two_as2);
-                    rfc[i] = det_exp(-final_costs[i] * final_costs[i] / beta) * pr;
+                    const float pr = prior_term(lm, di - depth_prior, ac, two_ds2, two_as2);
+                    rfc[i] = m_exp(lm, m_div(lm, -final_costs[i] * final_costs[i], beta)) * pr;
                 }
             }
             int max_idx = 0;
@@ -887,10 +978,10 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
                     }
             }
             const float ac = (pp.x * cur.x + pp.y * cur.y) + pp.z * cur.z;
-            const float pr = prior_term(depth_now - depth_prior, ac, two_ds2, two_as2);
-            const float rc_now = det_exp(-cost_now * cost_now / beta) * pr;
+            const float pr = prior_term(lm, depth_now - depth_prior, ac, two_ds2, two_as2);
+            const float rc_now = m_exp(lm, m_div(lm, -cost_now * cost_now, beta)) * pr;
             if (flag[max_idx]) {
-                const float db = depth_from_plane(cam, cand[max_idx], px, py);
+                const float db = depth_from_plane(cam, cand[max_idx], px, py, lm);
                 if (db >= prm.depth_min && db <= prm.depth_max && rfc[max_idx] > rc_now) {
                     // ref .cu:950 re-declares depth_now inside this block, so the
                     // assignment at :961 hits the shadow: the depth handed to the
@@ -902,7 +993,7 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
                 }
             }
         } else if (flag[min_idx]) {
-            const float db = depth_from_plane(cam, cand[min_idx], px, py);
+            const float db = depth_from_plane(cam, cand[min_idx], px, py, lm);
             if (db >= prm.depth_min && db <= prm.depth_max && final_costs[min_idx] < cost_now) {
                 depth_now = db;
                 plane_now = cand[min_idx];
@@ -912,7 +1003,7 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
     }
     // -- plain acceptance (ref .cu:981-991)
     if (!prior && flag[min_idx]) {
-        const float db = depth_from_plane(cam, cand[min_idx], px, py);
+        const float db = depth_from_plane(cam, cand[min_idx], px, py, lm);
         if (db >= prm.depth_min && db <= prm.depth_max && final_costs[min_idx] < cost_now) {
             depth_now = db;
             plane_now = cand[min_idx];
@@ -931,18 +1022,18 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
         F4 n_rand;
         if (masked) {
             pp = c.prior[idx];
-            depth_prior = depth_from_plane(cam, pp, px, py);
+            depth_prior = depth_from_plane(cam, pp, px, py, lm);
             // ref .cu:658-659: drawn, then always overwritten (missing else, quirk a-10 i)
             depth_rand = (rng_uniform(g) * 6.0f) * depth_sigma + (depth_prior - 3.0f * depth_sigma);
-            n_rand = perturbed_normal(cam, px, py, pp, g, angle_sigma);
+            n_rand = perturbed_normal(cam, px, py, pp, g, angle_sigma, lm);
         }
         depth_rand = rng_uniform(g) * (prm.depth_max - prm.depth_min) + prm.depth_min;
-        n_rand = random_normal(cam, px, py, g);
+        n_rand = random_normal(cam, px, py, g, lm);
 
         const float dmin_p = (1.0f - perturbation) * depth_now;
         const float dmax_p = (1.0f + perturbation) * depth_now;
         const float depth_pert = rng_uniform(g) * (dmax_p - dmin_p) + dmin_p;  // loop never repeats (quirk a-10 ii)
-        const F4 n_pert = perturbed_normal(cam, px, py, plane_now, g, 0.06283185f /* 0.02*pi */);
+        const F4 n_pert = perturbed_normal(cam, px, py, plane_now, g, 0.06283185f /* 0.02*pi */, lm);
 
         const float cost_now_at_refinement_start = cost_now;
         if (g_stat_wmask) {
@@ -960,16 +1051,16 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
             stat_last_masked = -1;
             for (int i = 0; i < 5; ++i) {
                 F4 tp = normals5[i];
-                tp.w = plane_offset(cam, px, py, depths5[i], tp);
-                const float dbs = depth_from_plane(cam, tp, px, py);
+                tp.w = plane_offset(cam, px, py, depths5[i], tp, lm);
+                const float dbs = depth_from_plane(cam, tp, px, py, lm);
                 const float ac = (pp.x * tp.x + pp.y * tp.y) + pp.z * tp.z;
-                const float pr = prior_term(depths5[i] - depth_prior, ac, two_ds2, two_as2);
+                const float pr = prior_term(lm, depths5[i] - depth_prior, ac, two_ds2, two_as2);
                 if (dbs >= prm.depth_min && dbs <= prm.depth_max && pr > 0.0f) stat_last_masked = i;
             }
         }
         for (int i = 0; i < 5; ++i) {
             F4 tp = normals5[i];
-            tp.w = plane_offset(cam, px, py, depths5[i], tp);
+            tp.w = plane_offset(cam, px, py, depths5[i], tp, lm);
             float m[3];
             plane_to_m(c, tp, m);
             float cv[kMaxViews];
@@ -978,7 +1069,7 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
             int stat_death = V;
             if (g_stat_death && masked && restricted_cost > 0.0f) {  // before any view: the prior term alone may already be too small
                 const float ac0 = (pp.x * tp.x + pp.y * tp.y) + pp.z * tp.z;
-                const float pr0 = prior_term(depths5[i] - depth_prior, ac0, two_ds2, two_as2);
+                const float pr0 = prior_term(lm, depths5[i] - depth_prior, ac0, two_ds2, two_as2);
                 if (!(pr0 * 1.000001f > restricted_cost)) stat_death = -1;
             }
             const float stat_cost_start = cost_now_at_refinement_start;
@@ -991,23 +1082,23 @@ void update_pixel(Ctx& c, const Params& prm, uint64_t seed, uint32_t launch, int
                     } else {
                         tc += view_w[v] * cv[v];
                     }
-                    if (stat_death == V && !masked && tc / weight_norm >= stat_cost_start) stat_death = v;
+                    if (stat_death == V && !masked && m_div(lm, tc, weight_norm) >= stat_cost_start) stat_death = v;
                 }
             }
             if (g_stat_death) {
-                const float dbs = depth_from_plane(cam, tp, px, py);
+                const float dbs = depth_from_plane(cam, tp, px, py, lm);
                 int8_t dv = (int8_t)((dbs >= prm.depth_min && dbs <= prm.depth_max) ? stat_death : -1);
                 if (stat_death == -1) dv = -1;
                 if (stat_last_masked != -2) dv = (int8_t)(i == stat_last_masked ? V : -1);
                 g_stat_death[(size_t)idx * 5 + i] = dv;
             }
-            tc /= weight_norm;
-            if (geom) tg /= weight_norm;
-            const float db = depth_from_plane(cam, tp, px, py);
+            tc = m_div(lm, tc, weight_norm);
+            if (geom) tg = m_div(lm, tg, weight_norm);
+            const float db = depth_from_plane(cam, tp, px, py, lm);
             if (masked) {
                 const float ac = (pp.x * tp.x + pp.y * tp.y) + pp.z * tp.z;
-                const float pr = prior_term(depths5[i] - depth_prior, ac, two_ds2, two_as2);
-                const float rtc = det_exp(-tc * tc / beta) * pr;
+                const float pr = prior_term(lm, depths5[i] - depth_prior, ac, two_ds2, two_as2);
+                const float rtc = m_exp(lm, m_div(lm, -tc * tc, beta)) * pr;
                 if (db >= prm.depth_min && db <= prm.depth_max && rtc > restricted_cost) {
                     plane_now = tp;  // restricted_cost is never raised (quirk a-10 iv)
                     cost_now = tc;
@@ -1029,7 +1120,7 @@ void depth_normal_pixel(Ctx& c, int px, int py) {
     const int idx = py * c.W + px;
     const Camera& cam = c.cams[0];
     F4 pl = c.planes[idx];
-    pl.w = depth_from_plane(cam, pl, px, py);
+    pl.w = depth_from_plane(cam, pl, px, py, c.literal_mode);
     F4 o;
     o.x = (cam.R[0] * pl.x + cam.R[3] * pl.y) + cam.R[6] * pl.z;
     o.y = (cam.R[1] * pl.x + cam.R[4] * pl.y) + cam.R[7] * pl.z;
@@ -1378,6 +1469,22 @@ int orc_eval_geom(orc_ctx* h, const void* params, const float* planes_cam4, floa
         for (int x = 0; x < c.W; ++x) {
             const F4 pl = ((const F4*)planes_cam4)[(size_t)y * c.W + x];
             for (int v = 0; v < V; ++v) out[(size_t)v * wh + (size_t)y * c.W + x] = geom_cost(c, v, pl, x, y);
+        }
+    return 0;
+}
+
+// the same with the reference's literal chain through world coordinates (geom_cost_literal): measures the canonical form
+int orc_eval_geom_literal(orc_ctx* h, const void* params, const float* planes_cam4, float* out) {
+    Ctx& c = h->c;
+    const Params& prm = *(const Params*)params;
+    if ((int)c.depths.size() != c.n_img - 1) { c.err = "need source depth maps"; return -4; }
+    const int V = prm.num_images - 1;
+    const size_t wh = (size_t)c.W * c.H;
+#pragma omp parallel for schedule(dynamic, 2)
+    for (int y = 0; y < c.H; ++y)
+        for (int x = 0; x < c.W; ++x) {
+            const F4 pl = ((const F4*)planes_cam4)[(size_t)y * c.W + x];
+            for (int v = 0; v < V; ++v) out[(size_t)v * wh + (size_t)y * c.W + x] = geom_cost_literal(c, v, pl, x, y);
         }
     return 0;
 }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/pm_golden_v2.npz from the CPU oracle.
+"""Generates tests/golden/pm_golden_v3.npz from the CPU oracle.
 
 The reference holds no golden vectors for this path and cannot be run here
 (DESIGN.md 3.7), so these are regression pins of the oracle's
@@ -89,8 +89,8 @@ def main():
         prm.max_iterations = 3
         h.run(prm, SEED + 2)
         out[f"{tag}_prior_planes"], out[f"{tag}_prior_costs"] = h.get()
-    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pm_golden_v2.npz"), **out)
-    print("wrote pm_golden_v2.npz with", len(out), "arrays")
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pm_golden_v3.npz"), **out)
+    print("wrote pm_golden_v3.npz with", len(out), "arrays")
 
 
 if __name__ == "__main__":

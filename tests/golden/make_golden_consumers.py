@@ -2,7 +2,7 @@
 """Generates tests/golden/consumers_golden_v1.npz: regression pins for the rows either side of the hot path.
 
   fusion / sky filter   the CPU oracle's outputs (oracle/fusion_oracle.cpp) on a small seeded scene -- like
-                        pm_golden_v2.npz these pin the oracle's own arithmetic (the reference cannot be run here);
+                        pm_golden_v3.npz these pin the oracle's own arithmetic (the reference cannot be run here);
   JPEG                  three small JPEG files and the pixels libjpeg-turbo (through PIL) decodes from them -- these
                         ARE third-party answers: the decoder of mp-mvs_amd/host/jpeg_decode.cpp must reproduce them.
 

@@ -1,11 +1,11 @@
-"""Replays the committed fixture tests/golden/pm_golden_v2.npz on a PatchMatch
+"""Replays the committed fixture tests/golden/pm_golden_v3.npz on a PatchMatch
 handle (CPU oracle or HIP context) and checks every stored output bit for bit."""
 import ctypes
 import os
 
 import numpy as np
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pm_golden_v2.npz")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pm_golden_v3.npz")
 SEED = 20240309
 
 

@@ -1,0 +1,23 @@
+#!/bin/bash
+# One rocprofv3 --pmc pass (with --kernel-trace only) of a short cfg-1 bench run, per-kernel counter averages printed:
+#   tools/pmc_pass.sh <tag> <real|variant-name under build/> COUNTER [COUNTER ...]      -> gpurun_out/pmc_<tag>/summary.txt
+#   PMC_SCRIPT="tools/bench_scales.py" tools/pmc_pass.sh ...   profiles another python script (all update modes), one row per
+#   template instantiation
+# The program itself follows `--`; the library override travels in the environment of rocprofv3 (no env / bash -c hop).
+set -o pipefail
+TAG=$1; VAR=$2; shift 2
+cd ${GRAFT_REPO_ROOT:?}
+OUT=$PWD/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+if [ "$VAR" != real ]; then export MPMVS_HIP_LIB=$PWD/build/libmpmvs_hip_$VAR.so; fi
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+if [ -n "$PMC_SCRIPT" ]; then
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_$TAG -- python3 $PMC_SCRIPT > $OUT/line.json 2> $OUT/err.txt || echo "pass failed" >> $OUT/err.txt
+  echo "python3 $PMC_SCRIPT  [library: $VAR]" > $OUT/command.txt
+  python3 tools/summarize_prof.py $OUT --by-variant > $OUT/summary.txt 2>&1
+else
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_$TAG -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/line.json 2> $OUT/err.txt || echo "pass failed" >> $OUT/err.txt
+  echo "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary  [library: $VAR]" > $OUT/command.txt
+  python3 tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+fi
+cat $OUT/summary.txt

@@ -22,7 +22,15 @@ for key, path in (("command", os.path.join(out, "command.txt")), ("git_head", os
         print(f"# {key}: {open(path).read().strip()}")
 
 
+BY_VARIANT = "--by-variant" in sys.argv   # keep the template arguments of k_update / k_init (one row per instantiation)
+
+
 def short(name):
+    if BY_VARIANT and ("k_update" in name or "k_init" in name):
+        import re
+        m = re.search(r"(k_update|k_init)<([^>]*)>", name)
+        if m:
+            return m.group(1) + "<" + m.group(2).replace(" ", "") + ">"
     for key in ("k_update", "k_init", "k_filter", "k_depth_normal", "k_pad", "k_export", "k_eval", "k_prior_raster", "k_prior"):
         if key in name:
             return key
@@ -55,7 +63,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
             meta[k] = (row.get("VGPR_Count"), row.get("Accum_VGPR_Count"), row.get("SGPR_Count"), row.get("Scratch_Size"), row.get("LDS_Block_Size"))
     print(f"== {os.path.basename(d)} (per-dispatch average) ==")
     for k in agg:
-        if k not in ("k_update", "k_init"):
+        if not (k.startswith("k_update") or k.startswith("k_init")):
             continue
         print(f"  {k}  vgpr/agpr/sgpr/scratch/lds = {meta[k]}")
         for c, v in agg[k].items():
