@@ -55,8 +55,9 @@ def set_num_threads(n):
 
 
 def set_literal_mode(handle, mode):
-    """0: canonical NCC (default); 1: every NCC evaluation of run()/step() in the reference's literal operation order with libm;
-    2: additionally CUDA's 8-bit texture interpolation fractions.  Measurement only (end-to-end statistics)."""
+    """0: canonical arithmetic (default); 1: the WHOLE path of run()/step() in the reference's literal operation order with IEEE
+    operations and libm; 2: additionally CUDA's 8-bit texture interpolation fractions; 3: a model of the reference's
+    --use_fast_math build (approximate exp / sin / cos / reciprocal, contracted multiply-adds, 8-bit fractions).  Measurement only."""
     l, _ = lib()
     l.orc_set_literal_mode.restype = C.c_int
     l.orc_set_literal_mode.argtypes = [C.c_void_p, C.c_int]
@@ -64,13 +65,16 @@ def set_literal_mode(handle, mode):
         raise RuntimeError("orc_set_literal_mode failed")
 
 
-def eval_ncc_literal(handle, params, planes_cam, scale, quantize_fraction=False):
-    """NCC in the reference's literal operation order (see pm_oracle.cpp); measurement only"""
+def eval_ncc_literal(handle, params, planes_cam, scale, quantize_fraction=False, mode=None):
+    """NCC in the reference's literal operation order (see pm_oracle.cpp); measurement only.  mode 1: IEEE + libm; 2: with CUDA's
+    8-bit texture fractions (= quantize_fraction); 3: the fast-math model of the reference's build"""
+    if mode is not None:
+        quantize_fraction = int(mode) - 1
     import numpy as np
     l, _ = lib()
     p = np.ascontiguousarray(planes_cam, np.float32)
     out = np.empty((params.num_images - 1, handle.H, handle.W), np.float32)
-    rc = l.orc_eval_ncc_literal(handle._ctx, C.byref(params), p.ctypes.data, int(scale), 1 if quantize_fraction else 0, out.ctypes.data)
+    rc = l.orc_eval_ncc_literal(handle._ctx, C.byref(params), p.ctypes.data, int(scale), int(quantize_fraction), out.ctypes.data)
     if rc != 0:
         raise RuntimeError(f"orc_eval_ncc_literal failed ({rc})")
     return out

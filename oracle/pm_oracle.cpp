@@ -181,22 +181,23 @@ inline float det_acos(float x) {
 //      multiply-adds where nvcc contracts, 8-bit texture fractions.  The approximate instructions are modelled by correctly
 //      rounded functions of the ROUNDED intermediate (their error bounds are 1-2 ulp; which ulp the hardware picks is not
 //      published): mode 3 is "a second build of the reference's formulas", the control that shows how many pixels the
-//      reference's own arithmetic variants flip against each other (tests/test_literal_gpu.py).
+//      reference's own arithmetic variants flip against each other (tests/test_literal_gpu.py);
+//   4  = 3 without the 8-bit texture fractions: the arithmetic of the build alone.
 // ---------------------------------------------------------------------------
-inline float m_div(int lm, float a, float b) { return lm == 3 ? a * (1.0f / b) : a / b; }
+inline float m_div(int lm, float a, float b) { return lm >= 3 ? a * (1.0f / b) : a / b; }
 inline float m_exp(int lm, float x) {
     if (lm == 0) return det_exp(x);
-    if (lm == 3) return (float)exp2((double)(x * 1.44269504f));
+    if (lm >= 3) return (float)exp2((double)(x * 1.44269504f));
     return expf(x);
 }
 inline float m_sin(int lm, float a) {
     if (lm == 0) return det_sin(a);
-    if (lm == 3) return rintf((float)sin((double)a) * 4194304.0f) / 4194304.0f;
+    if (lm >= 3) return rintf((float)sin((double)a) * 4194304.0f) / 4194304.0f;
     return sinf(a);
 }
 inline float m_cos(int lm, float a) {
     if (lm == 0) return det_cos(a);
-    if (lm == 3) return rintf((float)cos((double)a) * 4194304.0f) / 4194304.0f;
+    if (lm >= 3) return rintf((float)cos((double)a) * 4194304.0f) / 4194304.0f;
     return cosf(a);
 }
 inline float m_acos(int lm, float x) { return lm == 0 ? det_acos(x) : acosf(x); }
@@ -280,7 +281,7 @@ struct Ctx {
     std::vector<F4> prior;
     std::vector<uint32_t> mask;
     bool have_prior = false;
-    int literal_mode = 0;  // 0 canonical NCC; 1 literal restatement; 2 literal + 8-bit texture fractions (measurement only)
+    int literal_mode = 0;  // 0 canonical; 1-3 measurement modes of the WHOLE path (see m_div / m_exp above)
     std::string err;
 };
 
@@ -444,7 +445,7 @@ inline F4 perturbed_normal(const Camera& cam, int px, int py, const F4& normal, 
 static thread_local F4 tl_plane;
 static thread_local int tl_scale = 0;
 static thread_local const Params* tl_prm = nullptr;
-float literal_ncc(const Ctx& c, const Params& prm, int px, int py, const F4& pl, int v, int scale, int quantize);
+float literal_ncc(const Ctx& c, const Params& prm, int px, int py, const F4& pl, int v, int scale, int lm);
 
 struct RefWin {
     float w[36];
@@ -522,7 +523,7 @@ inline void plane_to_m(const Ctx& c, const F4& pl, float m[3]) {
 
 // ref .cu:325-414 ComputeBilateralNCC for one (plane, source view)
 inline float ncc_cost(const Ctx& c, const RefWin& rw, int px, int py, const float m[3], int v /*0-based source*/) {
-    if (c.literal_mode) return literal_ncc(c, *tl_prm, px, py, tl_plane, v, tl_scale, c.literal_mode == 2);
+    if (c.literal_mode) return literal_ncc(c, *tl_prm, px, py, tl_plane, v, tl_scale, c.literal_mode);
     const ViewConst& vc = c.vc[v];
     const Image& src = c.imgs[v + 1];
     float Hm[9];
@@ -602,9 +603,9 @@ inline float ncc_cost(const Ctx& c, const RefWin& rw, int px, int py, const floa
 // ---------------------------------------------------------------------------
 // Geometric consistency (ref .cu:582-640)
 // ---------------------------------------------------------------------------
-inline void backproject(const Camera& cam, float x, float y, float depth, float P[3]) {
-    const float X0 = (depth * (x - cam.K[2])) / cam.K[0];
-    const float X1 = (depth * (y - cam.K[5])) / cam.K[4];
+inline void backproject(const Camera& cam, float x, float y, float depth, float P[3], int lm = 0) {
+    const float X0 = m_div(lm, depth * (x - cam.K[2]), cam.K[0]);
+    const float X1 = m_div(lm, depth * (y - cam.K[5]), cam.K[4]);
     const float X2 = depth;
     const float t0 = (cam.R[0] * X0 + cam.R[3] * X1) + cam.R[6] * X2;
     const float t1 = (cam.R[1] * X0 + cam.R[4] * X1) + cam.R[7] * X2;
@@ -613,13 +614,13 @@ inline void backproject(const Camera& cam, float x, float y, float depth, float 
     P[1] = t1 + cam.C[1];
     P[2] = t2 + cam.C[2];
 }
-inline void project(const Camera& cam, const float P[3], float& u, float& v) {
+inline void project(const Camera& cam, const float P[3], float& u, float& v, int lm = 0) {
     const float t0 = ((cam.R[0] * P[0] + cam.R[1] * P[1]) + cam.R[2] * P[2]) + cam.t[0];
     const float t1 = ((cam.R[3] * P[0] + cam.R[4] * P[1]) + cam.R[5] * P[2]) + cam.t[1];
     const float t2 = ((cam.R[6] * P[0] + cam.R[7] * P[1]) + cam.R[8] * P[2]) + cam.t[2];
     const float d = (cam.K[6] * t0 + cam.K[7] * t1) + cam.K[8] * t2;
-    u = ((cam.K[0] * t0 + cam.K[1] * t1) + cam.K[2] * t2) / d;
-    v = ((cam.K[3] * t0 + cam.K[4] * t1) + cam.K[5] * t2) / d;
+    u = m_div(lm, (cam.K[0] * t0 + cam.K[1] * t1) + cam.K[2] * t2, d);
+    v = m_div(lm, (cam.K[3] * t0 + cam.K[4] * t1) + cam.K[5] * t2, d);
 }
 // the reference's own chain through world coordinates (ref .cu:617-640), IEEE operations in the reference's order: the LITERAL
 // form, used when Ctx::literal_mode != 0 and by the probe that measures the distance of the canonical form below from it
@@ -627,11 +628,12 @@ inline float geom_cost_literal(const Ctx& c, int v /*0-based source*/, const F4&
     const Camera& rc = c.cams[0];
     const Camera& sc = c.cams[v + 1];
     const Image& dm = c.depths[v];
-    const float depth = depth_from_plane(rc, pl, px, py);
+    const int lm = c.literal_mode >= 3 ? 3 : 1;  // the probe (orc_eval_geom_literal) calls it in mode 0 as well: IEEE then
+    const float depth = depth_from_plane(rc, pl, px, py, lm);
     float Pw[3];
-    backproject(rc, (float)px, (float)py, depth, Pw);
+    backproject(rc, (float)px, (float)py, depth, Pw, lm);
     float su, sv;
-    project(sc, Pw, su, sv);
+    project(sc, Pw, su, sv, lm);
     // nearest texel, truncation toward zero, clamp addressing (ref .cu:626)
     float qx = (su >= 0.0f) ? su : 0.0f;
     qx = (qx <= (float)(dm.w - 1)) ? qx : (float)(dm.w - 1);
@@ -640,9 +642,9 @@ inline float geom_cost_literal(const Ctx& c, int v /*0-based source*/, const F4&
     const float sd = dm.px[(size_t)(int)qy * dm.w + (int)qx];
     if (sd == 0.0f) return 3.0f;
     float Ps[3];
-    backproject(sc, su, sv, sd, Ps);
+    backproject(sc, su, sv, sd, Ps, lm);
     float bu, bv;
-    project(rc, Ps, bu, bv);
+    project(rc, Ps, bu, bv, lm);
     const float dc = (float)px - bu, dr = (float)py - bv;
     const float e = sqrtf(dc * dc + dr * dr);
     return (e < 3.0f) ? e : 3.0f;
@@ -1272,33 +1274,39 @@ float literal_tex(const Image& im, float x, float y, int quantize) {
     return (1.0f - ax) * (1.0f - ay) * t00 + ax * (1.0f - ay) * t10 + (1.0f - ax) * ay * t01 + ax * ay * t11;
 }
 
-float literal_ncc(const Ctx& c, const Params& prm, int px, int py, const F4& pl, int v, int scale, int quantize) {
+// lm: 1 IEEE + libm; 2 the same with 8-bit texture fractions; 3 the fast-math model (m_div / m_exp, fused multiply-adds where
+// nvcc contracts a * b + c, 8-bit fractions); 4 = 3 without the 8-bit fractions
+float literal_ncc(const Ctx& c, const Params& prm, int px, int py, const F4& pl, int v, int scale, int lm) {
     const Camera& rc = c.cams[0];
     const Camera& sc = c.cams[v + 1];
+    const bool fast = lm >= 3;
+    const int quantize = lm == 2 || lm == 3;
+    auto mad = [&](float a, float b, float acc) { return fast ? fmaf(a, b, acc) : acc + a * b; };
     // R_rel = R_s R_r^T, t_rel = R_s (C_r - C_s)
     float Rr[9], tr[3], Cd[3];
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) Rr[i * 3 + j] = sc.R[i * 3] * rc.R[j * 3] + sc.R[i * 3 + 1] * rc.R[j * 3 + 1] + sc.R[i * 3 + 2] * rc.R[j * 3 + 2];
+        for (int j = 0; j < 3; ++j) Rr[i * 3 + j] = mad(sc.R[i * 3 + 2], rc.R[j * 3 + 2], mad(sc.R[i * 3 + 1], rc.R[j * 3 + 1], sc.R[i * 3] * rc.R[j * 3]));
     for (int k = 0; k < 3; ++k) Cd[k] = rc.C[k] - sc.C[k];
-    for (int i = 0; i < 3; ++i) tr[i] = sc.R[i * 3] * Cd[0] + sc.R[i * 3 + 1] * Cd[1] + sc.R[i * 3 + 2] * Cd[2];
+    for (int i = 0; i < 3; ++i) tr[i] = mad(sc.R[i * 3 + 2], Cd[2], mad(sc.R[i * 3 + 1], Cd[1], sc.R[i * 3] * Cd[0]));
     float Hm[9], T[9];
     const float n3[3] = {pl.x, pl.y, pl.z};
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) Hm[i * 3 + j] = Rr[i * 3 + j] - tr[i] * n3[j] / pl.w;
+        for (int j = 0; j < 3; ++j) Hm[i * 3 + j] = Rr[i * 3 + j] - m_div(lm, tr[i] * n3[j], pl.w);
     for (int i = 0; i < 3; ++i) {
-        T[i * 3 + 0] = Hm[i * 3 + 0] / rc.K[0];
-        T[i * 3 + 1] = Hm[i * 3 + 1] / rc.K[4];
-        T[i * 3 + 2] = -Hm[i * 3 + 0] * rc.K[2] / rc.K[0] - Hm[i * 3 + 1] * rc.K[5] / rc.K[4] + Hm[i * 3 + 2];
+        T[i * 3 + 0] = m_div(lm, Hm[i * 3 + 0], rc.K[0]);
+        T[i * 3 + 1] = m_div(lm, Hm[i * 3 + 1], rc.K[4]);
+        T[i * 3 + 2] = -m_div(lm, Hm[i * 3 + 0] * rc.K[2], rc.K[0]) - m_div(lm, Hm[i * 3 + 1] * rc.K[5], rc.K[4]) + Hm[i * 3 + 2];
     }
     for (int j = 0; j < 3; ++j) {
-        Hm[0 + j] = sc.K[0] * T[0 + j] + sc.K[2] * T[6 + j];
-        Hm[3 + j] = sc.K[4] * T[3 + j] + sc.K[5] * T[6 + j];
+        Hm[0 + j] = mad(sc.K[2], T[6 + j], sc.K[0] * T[0 + j]);
+        Hm[3 + j] = mad(sc.K[5], T[6 + j], sc.K[4] * T[3 + j]);
         Hm[6 + j] = sc.K[8] * T[6 + j];
     }
     auto warp = [&](int x, int y, float& u, float& w) {
-        const float a = Hm[0] * x + Hm[1] * y + Hm[2], b = Hm[3] * x + Hm[4] * y + Hm[5], z = Hm[6] * x + Hm[7] * y + Hm[8];
-        u = a / z;
-        w = b / z;
+        const float fx = (float)x, fy = (float)y;
+        const float a = mad(Hm[1], fy, Hm[0] * fx) + Hm[2], b = mad(Hm[4], fy, Hm[3] * fx) + Hm[5], z = mad(Hm[7], fy, Hm[6] * fx) + Hm[8];
+        u = m_div(lm, a, z);
+        w = m_div(lm, b, z);
     };
     float cu, cv;
     warp(px, py, cu, cv);
@@ -1318,22 +1326,22 @@ float literal_ncc(const Ctx& c, const Params& prm, int px, int py, const F4& pl,
             warp(px + i, py + j, u, w2);
             const float sp = literal_tex(src, u, w2, quantize);
             const float sd = sqrtf((float)i * (float)i + (float)j * (float)j);
-            const float wt = expf(-sd / (2.0f * prm.sigma_spatial * prm.sigma_spatial) - fabsf(rp - centre) / (2.0f * prm.sigma_color * prm.sigma_color));
-            r_r += wt * rp;
-            r_rr += wt * rp * rp;
-            r_s += wt * sp;
-            r_ss += wt * sp * sp;
-            r_rs += wt * rp * sp;
+            const float wt = m_exp(lm, -m_div(lm, sd, 2.0f * prm.sigma_spatial * prm.sigma_spatial) - m_div(lm, fabsf(rp - centre), 2.0f * prm.sigma_color * prm.sigma_color));
+            r_r = mad(wt, rp, r_r);
+            r_rr = mad(wt * rp, rp, r_rr);
+            r_s = mad(wt, sp, r_s);
+            r_ss = mad(wt * sp, sp, r_ss);
+            r_rs = mad(wt * rp, sp, r_rs);
             r_w += wt;
         }
         s_r += r_r; s_rr += r_rr; s_s += r_s; s_ss += r_ss; s_rs += r_rs; s_w += r_w;
     }
-    const float inv = 1.0f / s_w;
+    const float inv = m_div(lm, 1.0f, s_w);
     s_r *= inv; s_rr *= inv; s_s *= inv; s_ss *= inv; s_rs *= inv;
-    const float var_r = s_rr - s_r * s_r, var_s = s_ss - s_s * s_s;
+    const float var_r = fast ? fmaf(-s_r, s_r, s_rr) : s_rr - s_r * s_r, var_s = fast ? fmaf(-s_s, s_s, s_ss) : s_ss - s_s * s_s;
     if (var_r < 1e-5f || var_s < 1e-5f) return 2.0f;
-    const float cov = s_rs - s_r * s_s;
-    return std::fmax(0.0f, std::fmin(2.0f, 1.0f - cov / sqrtf(var_r * var_s)));
+    const float cov = fast ? fmaf(-s_r, s_s, s_rs) : s_rs - s_r * s_s;
+    return std::fmax(0.0f, std::fmin(2.0f, 1.0f - m_div(lm, cov, sqrtf(var_r * var_s))));
 }
 
 }  // namespace
@@ -1490,11 +1498,12 @@ int orc_eval_geom_literal(orc_ctx* h, const void* params, const float* planes_ca
 }
 
 int orc_set_literal_mode(orc_ctx* h, int mode) {
-    if (!h || mode < 0 || mode > 2) return -1;
+    if (!h || mode < 0 || mode > 4) return -1;
     h->c.literal_mode = mode;
     return 0;
 }
 
+// quantize_fraction: 0 = mode 1 (IEEE + libm), 1 = mode 2 (+ 8-bit texture fractions), 2 = mode 3 (the fast-math model)
 int orc_eval_ncc_literal(orc_ctx* h, const void* params, const float* planes_cam4, int scale, int quantize_fraction, float* out) {
     Ctx& c = h->c;
     const Params& prm = *(const Params*)params;
@@ -1506,7 +1515,7 @@ int orc_eval_ncc_literal(orc_ctx* h, const void* params, const float* planes_cam
     for (int y = 0; y < c.H; ++y)
         for (int x = 0; x < c.W; ++x) {
             const F4 pl = ((const F4*)planes_cam4)[(size_t)y * c.W + x];
-            for (int v = 0; v < V; ++v) out[(size_t)v * wh + (size_t)y * c.W + x] = literal_ncc(c, prm, x, y, pl, v, scale, quantize_fraction);
+            for (int v = 0; v < V; ++v) out[(size_t)v * wh + (size_t)y * c.W + x] = literal_ncc(c, prm, x, y, pl, v, scale, 1 + quantize_fraction);
         }
     return 0;
 }

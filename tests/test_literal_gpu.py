@@ -11,13 +11,13 @@ T1  NCC costs (range [0, 2]) on a 400x300 cfg-1 scene, 8 views, window scales 0.
     8-bit fractions (mode 2) are a property of the sampler hardware, not of the formulas: they alone move costs by up to
     2e-3, so that bar is 99.9 % within 1e-3 and none beyond 3e-3.
 T2  one kernel step from an identical state (SURVEY 8c tier T2): InitializeScore and one BlackPixelUpdate in each of the three
-    modes, HIP path against the oracle computing every NCC literally.  Costs differ at the 1e-4 level, so a threshold count,
-    a sampled view, an arg-min or an acceptance test can flip at a pixel, and that pixel then carries a different -- equally
-    good -- plane.  Measured on the MI355X: the depth differs by more than 1e-3 at 1.3 % (photometric, from random planes),
-    4.6 % (geometric, from a converged state, where the candidates' costs are nearly equal) and 1.5 % (prior) of the pixels --
-    SURVEY's 0.5 % budget cannot hold against ANY second implementation of these formulas -- while the COSTS of the chosen
-    planes agree: |difference| > 1e-2 at fewer than 3e-4 of the pixels, mean cost equal to five digits.  Asserted: flips
-    <= 3 % / 8 % / 3 %, cost disagreement <= 1e-3 of the pixels, mean cost within 0.1 %; InitializeScore leaves identical planes.
+    modes, HIP path against the oracle computing the WHOLE step literally (round 4: every libm call, division and the geometric
+    chain, not only the NCC).  Costs differ at the 1e-4 level, so a threshold count, a sampled view, an arg-min or an acceptance
+    test can flip at a pixel, and that pixel then carries a different -- equally good -- plane.  How many pixels that is, is
+    measured against a CONTROL: the reference's formulas in IEEE arithmetic against the same formulas as the reference's own
+    build computes them (mode 4: a model of nvcc --use_fast_math arithmetic; mode 2: its texture hardware; mode 3: both).
+    Asserted: HIP vs literal flips <= 1.5 x the rate of the strictest control (fast-math arithmetic alone); cost disagreement (> 1e-2) <= 1e-3 of the pixels, mean cost
+    within 0.1 %; InitializeScore leaves identical planes.
 T3  the whole Run() schedule: individual decisions differ (ties flip, then the random walks diverge), the statistics must
     not: pixels within 1 % of the analytic ground-truth depth +-0.5 pp, mean matching cost +-2 %.
 """
@@ -48,7 +48,7 @@ def test_T1_ncc_costs_vs_literal_formulas(pm, oracle, scene):
     rng = np.random.default_rng(11)
     gt = sc.views[0].gt_depth.astype(np.float64)
     u, v = np.meshgrid(np.arange(W), np.arange(H))
-    worst = {1: 0.0, 2: 0.0}
+    worst = {1: 0.0, 2: 0.0, 3: 0.0}
     for depth, tilt in [(gt, 0.0), (gt * rng.uniform(0.9, 1.1, gt.shape), 0.3), (rng.uniform(dmin, dmax, gt.shape), 1.0)]:
         n = np.zeros((H, W, 3))
         n[..., 2] = -1.0
@@ -58,8 +58,8 @@ def test_T1_ncc_costs_vs_literal_formulas(pm, oracle, scene):
         planes = np.concatenate([n, -(n * X).sum(-1)[..., None]], -1).astype(np.float32)
         for scale in (0, 1, 2):
             hip = gpu.eval_ncc(prm, planes, scale)
-            for mode in (1, 2):
-                lit = oracle.eval_ncc_literal(cpu, prm, planes, scale, quantize_fraction=(mode == 2))
+            for mode in (1, 2, 3):
+                lit = oracle.eval_ncc_literal(cpu, prm, planes, scale, mode=mode)
                 both = (hip < 2.0) & (lit < 2.0)
                 assert both.mean() > 0.5
                 assert ((hip == 2.0) != (lit == 2.0)).mean() < 1e-3     # window centre on the image border / variance threshold
@@ -72,16 +72,23 @@ def test_T1_ncc_costs_vs_literal_formulas(pm, oracle, scene):
                 else:
                     assert (d > 1e-3).mean() <= 1e-3, (scale, tilt, float(d.max()))
                     assert d.max() < 3e-3
-    print(f"max |HIP - literal| = {worst[1]:.2e}, max |HIP - literal with 8-bit fractions| = {worst[2]:.2e}")
+    print(f"max |HIP - literal| = {worst[1]:.2e}, max |HIP - literal with 8-bit fractions| = {worst[2]:.2e}, max |HIP - fast-math model| = {worst[3]:.2e}")
 
 
-# SURVEY 8(c) budgeted <= 0.5 % of the pixels for this tier.  That budget does not hold against ANY second implementation of
-# these formulas (a cost difference of 1e-4 flips a threshold count, a sampled view or an acceptance test and the pixel then
-# carries a different, equally good plane), so the asserted limits below are wider -- a relaxation this build granted itself;
-# the test prints every measured fraction next to the budget so that it stays visible.
+# SURVEY 8(c) budgeted <= 0.5 % of the pixels for this tier.  That budget cannot hold against ANY second implementation of these
+# formulas: a cost difference of 1e-4 flips a threshold count, a sampled view, an arg-min or an acceptance test, and the pixel
+# then carries a different, equally good plane.  Since round 4 that statement is MEASURED instead of asserted: the oracle's
+# measurement modes cover the whole path (libm expf / sinf / cosf / acosf, rsqrt, the double `0.8 *` of ref .cu:832, every
+# division, the literal geometric chain), and mode 3 models the reference BINARY (nvcc --use_fast_math, ref CMakeLists.txt:18:
+# approximate exp / sin / cos / reciprocal, contracted multiply-adds, 8-bit texture fractions).  The control is the reference
+# against itself -- its formulas in IEEE arithmetic (mode 1) against the same formulas as its own build computes them (mode 3)
+# (mode 3), against its texture hardware alone (mode 2) and against its build's arithmetic alone (mode 4 = mode 3 without the 8-bit
+# fractions).  The HIP path may flip at most 1.5 x as many pixels against mode 1 as the reference's formulas flip against
+# themselves under fast-math ARITHMETIC alone -- the strictest of the three controls.  Measured (400x300, round 4): HIP vs literal
+# 1.30 % / 4.71 % / 1.48 % (photometric / geometric / prior); literal vs fast-math arithmetic 1.19 % / 4.49 % / 1.40 %; literal vs
+# 8-bit fractions 3.16 % / 9.31 % / 2.92 %.
 SURVEY_T2_BUDGET = 0.005
-LIMITS = {"photometric init": 0.0, "geometric init": 0.0, "prior init": 0.0, "photometric black update": 0.03, "geometric black update": 0.08,
-          "prior black update": 0.03}
+CONTROL_FACTOR = 1.5
 
 
 def test_T2_single_steps_vs_literal_formulas(pm, oracle, scene):
@@ -96,44 +103,55 @@ def test_T2_single_steps_vs_literal_formulas(pm, oracle, scene):
     for h in (gpu, cpu):
         h.set_src_depths(depths)
         h.set_prior(prior, mask)
-    worst, cost_stats = {}, {}
 
-    def mismatch(tag):
-        gp, gc = gpu.get()
-        cp, cc = cpu.get()
-        rel = np.abs(gp[..., 3] - cp[..., 3]) / np.maximum(np.abs(cp[..., 3]), 1e-6)
-        frac = float((rel > 1e-3).mean())
-        worst[tag] = frac
-        dc = np.abs(gc - cc)
-        cost_stats[tag] = (float((dc > 1e-2).mean()), float(dc.max()), float(gc.mean()), float(cc.mean()))
-        return frac
+    def flips(a, b):
+        rel = np.abs(a[0][..., 3] - b[0][..., 3]) / np.maximum(np.abs(b[0][..., 3]), 1e-6)
+        return float((rel > 1e-3).mean())
 
+    rows = []
     for mode_name, geom, planar in (("photometric", False, False), ("geometric", True, False), ("prior", False, True)):
         prm = pm.PatchMatchParams(num_images=V + 1, depth_min=dmin, depth_max=dmax, max_scale=0, geom_consistency=geom, planar_prior=planar)
-        # identical start state on both sides: a converged photometric result (canonical arithmetic on both: bit-identical)
+        # identical start state on every side: a converged photometric result (canonical arithmetic: bit-identical on both)
         p0 = pm.PatchMatchParams(num_images=V + 1, depth_min=dmin, depth_max=dmax, max_scale=0)
         for h in (gpu, cpu):
             h.run(p0, 7)
         s_planes, s_costs = cpu.get()
         assert np.array_equal(s_planes, gpu.get()[0])
-        oracle.set_literal_mode(cpu, 1)
-        try:
-            for h in (gpu, cpu):
+
+        def two_steps(h, literal_mode):
+            """InitializeScore, then one BlackPixelUpdate, from the saved state: (planes, costs) after each"""
+            if literal_mode:
+                oracle.set_literal_mode(h, literal_mode)
+            try:
                 h.set_state(s_planes, s_costs)
                 h.step(prm, 11, pm.KIND_INIT, 0, 0, 0)
-            mismatch(mode_name + " init")
-            for h in (gpu, cpu):
+                after_init = h.get()
                 h.step(prm, 11, pm.KIND_BLACK, 0, 0, 1)
-            mismatch(mode_name + " black update")
-        finally:
-            oracle.set_literal_mode(cpu, 0)
-    print("pixels whose depth differs by more than 1e-3 after one step, HIP vs literal (SURVEY budget %.1e; asserted limit in brackets): " % SURVEY_T2_BUDGET +
-          ", ".join(f"{k} {v:.2e} [{LIMITS[k]:.0e}]{' OVER SURVEY BUDGET' if v > SURVEY_T2_BUDGET else ''}" for k, v in worst.items()))
-    print("cost after the step (fraction |d| > 1e-2, max |d|, mean HIP, mean literal): " + ", ".join(f"{k} {v[0]:.2e} {v[1]:.3f} {v[2]:.5f} {v[3]:.5f}" for k, v in cost_stats.items()))
-    for tag, frac in worst.items():
-        assert frac <= LIMITS[tag], (tag, frac)
-        far, _, mean_hip, mean_lit = cost_stats[tag]
-        assert far <= 1e-3 and abs(mean_hip / mean_lit - 1.0) <= 1e-3, (tag, cost_stats[tag])
+                return after_init, h.get()
+            finally:
+                if literal_mode:
+                    oracle.set_literal_mode(h, 0)
+
+        hip_i, hip_u = two_steps(gpu, 0)
+        lit = {m: two_steps(cpu, m) for m in (1, 2, 3, 4)}
+        # InitializeScore: the planes are drawn / re-encoded, not selected: no flips at all against the IEEE formulas
+        f_init = flips(hip_i, lit[1][0])
+        f_hip = flips(hip_u, lit[1][1])
+        control = {"fast-math arithmetic": flips(lit[4][1], lit[1][1]), "8-bit fractions": flips(lit[2][1], lit[1][1]),
+                   "fast-math build (both)": flips(lit[3][1], lit[1][1])}
+        dc = np.abs(hip_u[1] - lit[1][1][1])
+        rows.append((mode_name, f_init, f_hip, control, float((dc > 1e-2).mean()), float(hip_u[1].mean()), float(lit[1][1][1].mean()), flips(hip_u, lit[3][1])))
+    print("T2, pixels whose depth differs by more than 1e-3 after one BlackPixelUpdate (SURVEY budget %.1e):" % SURVEY_T2_BUDGET)
+    for name, f_init, f_hip, control, far, mh, ml, f_hip3 in rows:
+        print(f"  {name}: HIP vs literal {f_hip:.2e}; the reference against itself: literal vs " +
+              ", vs ".join(f"{k} {v:.2e}" for k, v in control.items()) + f"; HIP vs fast-math model {f_hip3:.2e}; after InitializeScore {f_init:.1e}; "
+              f"costs: |d| > 1e-2 at {far:.1e} of the pixels, mean {mh:.5f} / {ml:.5f}")
+    for name, f_init, f_hip, control, far, mh, ml, f_hip3 in rows:
+        assert f_init <= (0.0 if name == "photometric" else 1e-4), (name, f_init)   # geometric / prior: depths re-derived through one division
+        floor = control["fast-math arithmetic"]   # the strictest control: arithmetic alone, the texture hardware flips 2-3 x more
+        assert floor > 0.0
+        assert f_hip <= CONTROL_FACTOR * floor, f"{name}: HIP flips {f_hip:.3e} of the pixels against the literal formulas, the reference's own variants {floor:.3e}"
+        assert far <= 1e-3 and abs(mh / ml - 1.0) <= 1e-3, (name, far, mh, ml)
 
 
 def test_T3_schedule_statistics_vs_literal_formulas(pm, oracle, scene):
@@ -141,7 +159,7 @@ def test_T3_schedule_statistics_vs_literal_formulas(pm, oracle, scene):
     gt = sc.views[0].gt_depth
     prm = pm.PatchMatchParams(num_images=V + 1, depth_min=dmin, depth_max=dmax, max_scale=2)
     stats = {}
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         acc, cost = [], []
         for seed in (1, 2):
             if mode == 0:
@@ -156,8 +174,8 @@ def test_T3_schedule_statistics_vs_literal_formulas(pm, oracle, scene):
             acc.append(float((rel < 0.01).mean()))
             cost.append(float(costs.mean()))
         stats[mode] = (np.mean(acc), np.mean(cost))
-    print("within 1 %% of GT / mean cost: HIP %.4f %.5f, literal %.4f %.5f, literal + 8-bit %.4f %.5f" % (stats[0] + stats[1] + stats[2]))
+    print("within 1 %% of GT / mean cost: HIP %.4f %.5f, literal %.4f %.5f, literal + 8-bit %.4f %.5f, fast-math model %.4f %.5f" % (stats[0] + stats[1] + stats[2] + stats[3]))
     assert stats[0][0] > 0.9                                              # the schedule converges on this scene
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         assert abs(stats[mode][0] - stats[0][0]) < 0.005, stats
         assert abs(stats[mode][1] / stats[0][1] - 1.0) < 0.02, stats

@@ -459,3 +459,49 @@ def test_refinement_rejection_rules_hold_in_fp32(pm, oracle):
     assert dead.any() and (~dead).any()
     assert not (rtc[dead] > rc[dead]).any()
     assert e.max() <= np.nextafter(np.nextafter(f32(1.0), f32(2.0)), f32(2.0))
+
+
+def test_T2_flip_rates_against_the_references_own_noise_floor(pm, oracle):
+    """SURVEY 8c tier T2 with its control, on the CPU (tests/test_literal_gpu.py runs the same with the HIP path in the role of
+    mode 0): one BlackPixelUpdate from an identical state in the canonical arithmetic (mode 0 = what the kernels compute, bit for
+    bit) and in the measurement modes of the WHOLE path -- 1 the reference's formulas with IEEE operations and libm, 4 the same
+    formulas as a --use_fast_math build computes them (approximate exp / reciprocal / sin / cos, contracted multiply-adds),
+    2 with the texture hardware's 8-bit fractions.  The pixels whose depth then differs by more than 1e-3 are decision flips
+    (threshold counts, sampled views, acceptance tests on costs that differ by 1e-4).  The canonical arithmetic must not flip
+    more than 1.5 x what the reference's formulas flip against themselves under fast-math arithmetic alone."""
+    W, H, V = 320, 240, 6
+    sc = pm.synth.make_problem_scene(W, H, n_src=V, quantize=True)
+    cams, imgs = sc.problem(0, list(range(1, V + 1)))
+    dmin, dmax = (float(v) for v in pm.synth.kernel_depth_range(cams[0]))
+    h = oracle.create()
+    h.set_views(cams, imgs)
+    rng = np.random.default_rng(5)
+    h.set_src_depths([sc.views[i].gt_depth * (1.0 + 0.005 * rng.standard_normal((H, W))).astype(np.float32) for i in range(1, V + 1)])
+    prior = np.zeros((H, W, 4), np.float32)
+    prior[..., 2] = -1.0
+    prior[..., 3] = sc.views[0].gt_depth
+    h.set_prior(prior, (rng.uniform(size=(H, W)) < 0.6).astype(np.uint32))
+
+    def flips(a, b):
+        return float((np.abs(a[..., 3] - b[..., 3]) / np.maximum(np.abs(b[..., 3]), 1e-6) > 1e-3).mean())
+
+    report = []
+    for name, geom, planar in (("photometric", False, False), ("geometric", True, False), ("prior", False, True)):
+        prm = pm.PatchMatchParams(num_images=V + 1, depth_min=dmin, depth_max=dmax, max_scale=0, geom_consistency=geom, planar_prior=planar)
+        h.run(pm.PatchMatchParams(num_images=V + 1, depth_min=dmin, depth_max=dmax, max_scale=0), 7)
+        s_planes, s_costs = h.get()
+        after = {}
+        for mode in (0, 1, 2, 4):
+            oracle.set_literal_mode(h, mode)
+            try:
+                h.set_state(s_planes, s_costs)
+                h.step(prm, 11, pm.KIND_INIT, 0, 0, 0)
+                h.step(prm, 11, pm.KIND_BLACK, 0, 0, 1)
+                after[mode] = h.get()[0]
+            finally:
+                oracle.set_literal_mode(h, 0)
+        canonical, fastmath, tex8 = flips(after[0], after[1]), flips(after[4], after[1]), flips(after[2], after[1])
+        report.append(f"{name}: canonical vs literal {canonical:.2e}, literal vs fast-math arithmetic {fastmath:.2e}, literal vs 8-bit fractions {tex8:.2e}")
+        assert fastmath > 0 and canonical <= 1.5 * fastmath, report[-1]
+        assert canonical <= tex8, report[-1]
+    print("\nT2 flip rates after one BlackPixelUpdate: " + "; ".join(report))
