@@ -60,6 +60,7 @@ struct mpmvs_ctx {
     bool all_u8 = false;
     std::vector<float*> d_depth; // dense source depth maps
     StateDev S{};
+    bool depth_plane_valid = false;  // S.depth mirrors planes[].w (true from GetDepthandNormal until planes are rewritten)
     float4* d_prior = nullptr;
     uint32_t* d_mask = nullptr;
     bool have_prior = false, have_depths = false;
@@ -230,6 +231,7 @@ static void free_views(mpmvs_ctx* c) {
     if (c->S.costs) (void)pool_free(c->S.costs);
     if (c->S.sel) (void)pool_free(c->S.sel);
     if (c->S.geom) (void)pool_free(c->S.geom);
+    if (c->S.depth) (void)pool_free(c->S.depth);
     if (c->d_prior) (void)pool_free(c->d_prior);
     if (c->d_mask) (void)pool_free(c->d_mask);
     c->S = StateDev{};
@@ -613,10 +615,11 @@ static int set_views_impl(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const f
     const size_t wh = (size_t)c->W * c->H;
     rc = -100;
     if (pool_malloc(&c->S.planes, wh * 16) == hipSuccess && pool_malloc(&c->S.costs, wh * 4) == hipSuccess &&
-        pool_malloc(&c->S.sel, wh * 4) == hipSuccess && pool_malloc(&c->S.geom, wh * 4) == hipSuccess &&
+        pool_malloc(&c->S.sel, wh * 4) == hipSuccess && pool_malloc(&c->S.geom, wh * 4) == hipSuccess && pool_malloc(&c->S.depth, wh * 4) == hipSuccess &&
         hipMemsetAsync(c->S.planes, 0, wh * 16, c->stream) == hipSuccess && hipMemsetAsync(c->S.costs, 0, wh * 4, c->stream) == hipSuccess &&
         hipMemsetAsync(c->S.sel, 0, wh * 4, c->stream) == hipSuccess && hipMemsetAsync(c->S.geom, 0, wh * 4, c->stream) == hipSuccess)
         rc = 0;
+    c->depth_plane_valid = false;
     if (rc) c->err = "allocation of the per-pixel state failed";
     const int rc_up = upload_problem(c);  // synchronises the stream (also on the failure path): both staging buffers are free again
     return rc ? rc : rc_up;
@@ -723,7 +726,10 @@ int mpmvs_set_state(mpmvs_ctx* c, const void* planes4, const void* costs) {
     HIPCHK(c, enter_device(c->device));
     if (!c->S.planes) return fail(c, -1, "set_views first");
     const size_t wh = (size_t)c->W * c->H;
-    if (planes4) HIPCHK(c, hipMemcpyAsync(c->S.planes, planes4, wh * 16, hipMemcpyHostToDevice, c->stream));
+    if (planes4) {
+        c->depth_plane_valid = false;
+        HIPCHK(c, hipMemcpyAsync(c->S.planes, planes4, wh * 16, hipMemcpyHostToDevice, c->stream));
+    }
     if (costs) HIPCHK(c, hipMemcpyAsync(c->S.costs, costs, wh * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -899,6 +905,7 @@ static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int 
     const dim3 grid_chk = checker_grid<true>(c, a);  // k_filter (checker_pixel<true>)
     switch (kind) {
         case MPMVS_KIND_INIT: {
+            c->depth_plane_valid = false;
             const size_t lds = ncc_lds_bytes(16, 16, a.scale);
             const int V = c->hP.V;
 #define PM_LAUNCH_INIT2(MV, SC)                                                                                             \
@@ -928,6 +935,7 @@ static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int 
         }
         case MPMVS_KIND_BLACK:
         case MPMVS_KIND_RED:
+            c->depth_plane_valid = false;
             if (p->geom_consistency)
                 launch_update<true, false>(c, a);
             else if (p->planar_prior)
@@ -937,9 +945,15 @@ static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int 
             break;
         case MPMVS_KIND_DEPTH_NORMAL:
             hipLaunchKernelGGL(k_depth_normal, grid_dense, blk, 0, c->stream, c->dP, c->S);
+            c->depth_plane_valid = true;
             break;
         case MPMVS_KIND_FILTER_BLACK:
         case MPMVS_KIND_FILTER_RED:
+            if (!c->depth_plane_valid) {  // a filter step on a state that did not come from GetDepthandNormal (mpmvs_set_state + mpmvs_step)
+                const int n = c->W * c->H;
+                hipLaunchKernelGGL(k_export_depth, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S.planes, c->S.depth, n);
+                c->depth_plane_valid = true;
+            }
             hipLaunchKernelGGL(k_filter, grid_chk, blk, 0, c->stream, c->dP, c->S, a);
             break;
         default:
@@ -1323,7 +1337,7 @@ int mpmvs_get_prior(mpmvs_ctx* c, void* prior4, void* mask) {
 }
 
 int mpmvs_math(int fn, const void* in, void* out, int n) {
-    if (fn < 0 || fn > 5 || n <= 0) return -1;
+    if (fn < 0 || fn > 6 || n <= 0) return -1;
     (void)hipGetLastError();  // drop a stale error of an earlier call (see enter_device)
     float *d_in = nullptr, *d_out = nullptr;
     if (hipMalloc(&d_in, (size_t)n * 4) != hipSuccess) return -100;

@@ -67,6 +67,7 @@ struct StateDev {
     float* geom;
     const float4* prior;
     const uint32_t* mask;
+    float* depth;  // dense copy of planes[].w after GetDepthandNormal: what the median filter gathers (4 instead of 16 bytes per tap)
 };
 
 // ---------------------------------------------------------------------------
@@ -142,6 +143,28 @@ PM_DEV float d_exp(float x) {
     if (!(x == x)) return y;
     const int ni = (int)n;
     return __uint_as_float(__float_as_uint(y) + ((uint32_t)ni << 23));
+}
+
+// d_exp without branches (the same value for every input): the window prologue calls it 36 times per pixel, and the three
+// exec-mask branches of d_exp cost more there than the polynomial
+PM_DEV float d_exp_select(float x) {
+    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    const float y = __builtin_fmaf(p, r * r, r) + 1.0f;
+    // n as an integer: only meaningful (and only used) for x in [-80, 80]; clamped first so that the conversion is defined
+    const int ni = (int)__builtin_amdgcn_fmed3f(n, -128.0f, 128.0f);
+    float e = __uint_as_float(__float_as_uint(y) + ((uint32_t)ni << 23));
+    e = (x == x) ? e : y;  // NaN propagates through y
+    e = (x > 80.0f) ? __uint_as_float(0x7f800000u) : e;
+    e = (x < -80.0f) ? 0.0f : e;
+    return e;
 }
 
 PM_DEV float d_sin(float a) {
@@ -368,7 +391,7 @@ PM_DEV void ref_window(float4* lw, TAP tap, const float (&spatial)[36], float tw
             const int dx = a * step - radius, dy = b * step - radius;
             const float r = tap(dx, dy);
             const float e = spatial[a * 6 + b] - __builtin_fabsf(r - rc) / two_sc;  // ref .cu:318-323
-            const float w = d_exp(e);
+            const float w = d_exp_select(e);
             const float wr = w * r;
             wv[b] = w;
             wrv[b] = wr;

@@ -791,6 +791,7 @@ __global__ __launch_bounds__(256) void k_depth_normal(const ProblemDev* __restri
     o.z = (P.cam.R[2] * pl.x + P.cam.R[5] * pl.y) + P.cam.R[8] * pl.z;
     o.w = pl.w;
     S.planes[idx] = o;
+    S.depth[idx] = pl.w;  // the filter's dense depth plane
 }
 
 // ---------------------------------------------------------------------------
@@ -836,6 +837,9 @@ PM_DEV float median21_rounds(float (&v)[21], float& lowest) {
     }
 }
 
+// The depths are gathered from the dense plane S.depth (written by k_depth_normal, kept in step with planes[].w here): 4 bytes
+// per tap instead of the .w of a 16-byte float4 (4 x over-fetch; 84 -> 40 us per launch).  Every tap has the other colour, so
+// the in-place update of one colour is race free in both arrays.
 __global__ __launch_bounds__(256) void k_filter(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
     const ProblemDev& P = *Pp;
     int x, y, x0, y0;
@@ -851,7 +855,7 @@ __global__ __launch_bounds__(256) void k_filter(const ProblemDev* __restrict__ P
         float sum = 0.0f;
 #pragma unroll
         for (int i = 0; i < 21; ++i) {
-            v[i] = S.planes[ctr + dy[i] * W + dx[i]].w;
+            v[i] = S.depth[ctr + dy[i] * W + dx[i]];
             sum += v[i];
         }
         float lowest = v[0];
@@ -860,14 +864,15 @@ __global__ __launch_bounds__(256) void k_filter(const ProblemDev* __restrict__ P
         // else (a NaN or infinite depth shows in the sum, a zero or negative one in the minimum) takes the general path
         if (lowest > 0.0f && sum < 3.0e38f) {
             S.planes[ctr].w = med;
+            S.depth[ctr] = med;
             return;
         }
     }
     float f[21];
     int n = 0;
 #define PM_TAP(cond, off) \
-    if (cond) f[n++] = S.planes[ctr + (off)].w;
-    f[n++] = S.planes[ctr].w;
+    if (cond) f[n++] = S.depth[ctr + (off)];
+    f[n++] = S.depth[ctr];
     PM_TAP(y > 0, -W)
     PM_TAP(y > 2, -3 * W)
     PM_TAP(y > 4, -5 * W)
@@ -896,7 +901,9 @@ __global__ __launch_bounds__(256) void k_filter(const ProblemDev* __restrict__ P
         f[j] = tmp;
     }
     const int mid = n / 2;
-    S.planes[ctr].w = (n % 2 == 0) ? (f[mid - 1] + f[mid]) / 2.0f : f[mid];
+    const float med = (n % 2 == 0) ? (f[mid - 1] + f[mid]) / 2.0f : f[mid];
+    S.planes[ctr].w = med;
+    S.depth[ctr] = med;
 }
 
 // ---------------------------------------------------------------------------
@@ -1000,6 +1007,7 @@ __global__ void k_math(int fn, const float* __restrict__ in, float* __restrict__
         case 2: y = d_sin(x); break;
         case 3: y = d_cos(x); break;
         case 4: y = d_acos(x); break;
+        case 6: y = d_exp_select(x); break;  // the branch-free form of the window prologue: the same value as fn 1
         default: y = __builtin_amdgcn_fractf(x); break;
     }
     out[i] = y;

@@ -1532,6 +1532,7 @@ int orc_math(int fn, const float* in, float* out, int n) {
             case 3: y = det_cos(x); break;
             case 4: y = det_acos(x); break;
             case 5: y = det_fract(x); break;
+            case 6: y = det_exp(x); break;  // the kernels' branch-free exp (d_exp_select) must equal the canonical exp
             default: return -1;
         }
         out[i] = y;

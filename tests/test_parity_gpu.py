@@ -60,7 +60,7 @@ def random_planes(pm, cam, W, H, rng, dmin, dmax):
 # ---------------------------------------------------------------------------
 # canonical math + RNG
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("fn,lo,hi", [(0, -3000.0, 3000.0), (1, -90.0, 5.0), (2, -0.8, 0.8), (3, -0.8, 0.8), (4, -1.1, 1.1), (5, -2.0, 1700.0)])
+@pytest.mark.parametrize("fn,lo,hi", [(0, -3000.0, 3000.0), (1, -90.0, 5.0), (2, -0.8, 0.8), (3, -0.8, 0.8), (4, -1.1, 1.1), (5, -2.0, 1700.0), (6, -90.0, 90.0)])
 def test_math_bit_exact(pm, oracle, engine, fn, lo, hi):
     rng = np.random.default_rng(fn)
     x = rng.uniform(lo, hi, 200000).astype(np.float32)

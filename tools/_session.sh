@@ -1,5 +1,7 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r4f
-python -m pytest tests/test_literal_gpu.py -x -q -s > gpurun_out/r4f/literal.log 2>&1; echo "literal rc=$?"; grep -E "T2|max \||within 1|HIP vs|passed|failed" gpurun_out/r4f/literal.log | tail -12
-python -m pytest tests/test_fullsize_gpu.py -x -q --durations=5 > gpurun_out/r4f/fullsize.log 2>&1; echo "fullsize rc=$?"; tail -12 gpurun_out/r4f/fullsize.log
+mkdir -p gpurun_out/r4g
+python -m pytest tests/test_parity_gpu.py tests/test_golden_gpu.py tests/test_fuzz_gpu.py tests/test_boundary_gpu.py -x -q > gpurun_out/r4g/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r4g/pytest.log
+python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary > /dev/null 2>&1
+
+
