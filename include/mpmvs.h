@@ -154,6 +154,14 @@ int mpmvs_run(mpmvs_ctx* ctx, const mpmvs_params* params, uint64_t seed);
  * Run() accepts the buffer: it receives what cudaGeomCosts holds.  The cost maps are final after the last update launch and
  * travel while the median filter still runs.  Same results as mpmvs_run followed by mpmvs_get. */
 int mpmvs_run_get(mpmvs_ctx* ctx, const mpmvs_params* params, uint64_t seed, void* planes4, void* costs, void* geom_costs);
+/* Pipelined form of mpmvs_run_get for a caller that works through many Problems / seeds on one context (the reference's Run()
+ * ends with blocking cudaMemcpy calls, src/PatchMatch.cu:1246-1251: 38 MB at PCIe rate = 4 % of a cfg-1 step during which the
+ * GPU idles).  The call enqueues the launches of Run(), stages the result maps on the device and returns at once; the maps
+ * reach the (page-locked) host buffers on a second stream while the NEXT mpmvs_run_get_async of this context already runs.
+ * Consecutive calls need different host buffers; mpmvs_wait() returns when every outstanding call has delivered.  Between the
+ * first such call and mpmvs_wait() the context rejects every other entry point (-8).  Results: those of mpmvs_run_get. */
+int mpmvs_run_get_async(mpmvs_ctx* ctx, const mpmvs_params* params, uint64_t seed, void* planes4, void* costs, void* geom_costs);
+int mpmvs_wait(mpmvs_ctx* ctx);
 /* one kernel of Run(), for parity tests; launch_id selects the RNG stream the
  * way Run() numbers its launches (0 = InitializeScore, then in launch order) */
 int mpmvs_step(mpmvs_ctx* ctx, const mpmvs_params* params, uint64_t seed, int kind, int iter, int scale,

@@ -48,6 +48,12 @@ struct mpmvs_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // mpmvs_run_get: the cost maps go to the host while the median filter still runs
     hipEvent_t costs_final = nullptr;
+    // mpmvs_run_get_async: results are staged on the device so that the next Run() may start while they travel to the host
+    float4* stage_planes = nullptr;
+    float* stage_costs = nullptr;
+    float* stage_geom = nullptr;
+    hipEvent_t staged = nullptr, staging_free = nullptr;
+    int async_outstanding = 0;
     int n_img = 0, W = 0, H = 0;
     std::vector<mpmvs_camera> cams;
     ProblemDev hP;               // host mirror
@@ -98,6 +104,14 @@ static int fail(mpmvs_ctx* c, int code, const char* msg) {
     c->err = msg;
     return code;
 }
+
+// Start of every entry point: select the context's device, and refuse to touch a context whose pipelined Run()s
+// (mpmvs_run_get_async) are still in flight -- only further mpmvs_run_get_async calls and mpmvs_wait are allowed then.
+#define ENTER(ctx)                                                                                          \
+    do {                                                                                                    \
+        HIPCHK(ctx, enter_device((ctx)->device));                                                           \
+        if ((ctx)->async_outstanding) return fail(ctx, -8, "pipelined Run()s are in flight: call mpmvs_wait first"); \
+    } while (0)
 
 // ---------------------------------------------------------------------------
 // Device-buffer pool.  A context is created and destroyed per ProcessProblem call in the reference's flow (three times
@@ -232,6 +246,11 @@ static void free_views(mpmvs_ctx* c) {
     if (c->S.sel) (void)pool_free(c->S.sel);
     if (c->S.geom) (void)pool_free(c->S.geom);
     if (c->S.depth) (void)pool_free(c->S.depth);
+    if (c->stage_planes) (void)pool_free(c->stage_planes);
+    if (c->stage_costs) (void)pool_free(c->stage_costs);
+    if (c->stage_geom) (void)pool_free(c->stage_geom);
+    c->stage_planes = nullptr;
+    c->stage_costs = c->stage_geom = nullptr;
     if (c->d_prior) (void)pool_free(c->d_prior);
     if (c->d_mask) (void)pool_free(c->d_mask);
     c->S = StateDev{};
@@ -531,10 +550,13 @@ void mpmvs_destroy(mpmvs_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);  // a pipelined Run() nobody waited for
     free_views(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     if (c->dP) (void)hipFree(c->dP);
     if (c->costs_final) (void)hipEventDestroy(c->costs_final);
+    if (c->staged) (void)hipEventDestroy(c->staged);
+    if (c->staging_free) (void)hipEventDestroy(c->staging_free);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -627,7 +649,7 @@ static int set_views_impl(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const f
 
 int mpmvs_set_views(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* const* images, const size_t* pitch_bytes) {
     if (!c) return -1;
-    HIPCHK(c, enter_device(c->device));
+    ENTER(c);
     if (n < 2 || n - 1 > MPMVS_MAX_SRC_VIEWS) return fail(c, -1, "need 2..33 views");
     for (int i = 0; i < n; ++i) {
         if (cams[i].width <= 0 || cams[i].height <= 0 || !images[i]) return fail(c, -2, "bad image size or null image");
@@ -675,7 +697,7 @@ static int depth_slot(mpmvs_ctx* c, int i, int w, int h, bool replace) {
 
 int mpmvs_set_src_depths(mpmvs_ctx* c, int n_src, const float* const* depths, const int* widths, const int* heights, const size_t* pitch_bytes) {
     if (!c) return -1;
-    HIPCHK(c, enter_device(c->device));
+    ENTER(c);
     if (c->n_img < 2 || n_src != c->n_img - 1) return fail(c, -1, "n_src must equal the number of source views");
     (void)hipStreamSynchronize(c->stream);
     if ((int)c->d_depth.size() != n_src) {
@@ -700,7 +722,7 @@ int mpmvs_set_src_depths(mpmvs_ctx* c, int n_src, const float* const* depths, co
 
 int mpmvs_set_src_depths_device(mpmvs_ctx* c, int n_src, const float* const* d_depths, const int* widths, const int* heights) {
     if (!c) return -1;
-    HIPCHK(c, enter_device(c->device));
+    ENTER(c);
     if (c->n_img < 2 || n_src != c->n_img - 1) return fail(c, -1, "n_src must equal the number of source views");
     (void)hipStreamSynchronize(c->stream);
     if ((int)c->d_depth.size() != n_src) {
@@ -723,7 +745,7 @@ int mpmvs_set_src_depths_device(mpmvs_ctx* c, int n_src, const float* const* d_d
 
 int mpmvs_set_state(mpmvs_ctx* c, const void* planes4, const void* costs) {
     if (!c) return -1;
-    HIPCHK(c, enter_device(c->device));
+    ENTER(c);
     if (!c->S.planes) return fail(c, -1, "set_views first");
     const size_t wh = (size_t)c->W * c->H;
     if (planes4) {
@@ -737,7 +759,7 @@ int mpmvs_set_state(mpmvs_ctx* c, const void* planes4, const void* costs) {
 
 int mpmvs_set_selected_views(mpmvs_ctx* c, const void* sel) {
     if (!c) return -1;
-    HIPCHK(c, enter_device(c->device));
+    ENTER(c);
     if (!c->S.sel) return fail(c, -1, "set_views first");
     HIPCHK(c, hipMemcpyAsync(c->S.sel, sel, (size_t)c->W * c->H * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -746,7 +768,7 @@ int mpmvs_set_selected_views(mpmvs_ctx* c, const void* sel) {
 
 int mpmvs_set_geom_costs(mpmvs_ctx* c, const void* geom) {
     if (!c || !geom) return -1;
-    HIPCHK(c, enter_device(c->device));
+    ENTER(c);
     if (!c->S.geom) return fail(c, -1, "set_views first");
     HIPCHK(c, hipMemcpyAsync(c->S.geom, geom, (size_t)c->W * c->H * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -755,7 +777,7 @@ int mpmvs_set_geom_costs(mpmvs_ctx* c, const void* geom) {
 
 int mpmvs_set_prior(mpmvs_ctx* c, const void* prior4, const void* mask) {
     if (!c) return -1;
-    HIPCHK(c, enter_device(c->device));
+    ENTER(c);
     if (!c->S.planes) return fail(c, -1, "set_views first");
     const size_t wh = (size_t)c->W * c->H;
     if (!c->d_prior) HIPCHK(c, pool_malloc(&c->d_prior, wh * 16));
@@ -1042,7 +1064,7 @@ static int enqueue_run(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, void*
 // while GetDepthandNormal and the median filter still run; the planes follow on the main stream.
 static int run_impl(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, void* planes4, void* costs, void* geom) {
     if (!c || !p) return -1;
-    HIPCHK(c, enter_device(c->device));
+    ENTER(c);
     int rc = check_ready(c, p);
     if (rc) return rc;
     for (int k = 0; k < 6; ++k) {
@@ -1064,9 +1086,87 @@ int mpmvs_run_get(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, void* plan
     return run_impl(c, p, seed, planes4, costs, geom);
 }
 
-int mpmvs_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int kind, int iter, int scale, uint32_t launch_id) {
+// Pipelined Run(): the same launches, but the result maps are first copied into staging buffers on the device (46 MB, ~25 us) and
+// travel to the host from there on the copy stream, so the call returns at once and the NEXT Run() of this context -- which
+// overwrites the state with its InitializeScore -- may start while the previous result is still crossing PCIe (0.7 ms of a
+// 17 ms cfg-1 step otherwise spent waiting).  The caller gives consecutive calls different host buffers and collects with
+// mpmvs_wait(); in between the context accepts nothing but further mpmvs_run_get_async calls.  Same results as mpmvs_run_get.
+int mpmvs_run_get_async(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, void* planes4, void* costs, void* geom) {
     if (!c || !p) return -1;
     HIPCHK(c, enter_device(c->device));
+    int rc = check_ready(c, p);
+    if (rc) return rc;
+    const size_t wh = (size_t)c->W * c->H;
+    if (!c->stage_planes) {
+        if (pool_malloc(&c->stage_planes, wh * 16) != hipSuccess || pool_malloc(&c->stage_costs, wh * 4) != hipSuccess ||
+            pool_malloc(&c->stage_geom, wh * 4) != hipSuccess)
+            return fail(c, -100, "allocation of the staging buffers failed");
+    }
+    if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->staged) HIPCHK(c, hipEventCreateWithFlags(&c->staged, hipEventDisableTiming));
+    if (!c->staging_free) HIPCHK(c, hipEventCreateWithFlags(&c->staging_free, hipEventDisableTiming));
+    if (!c->async_outstanding)
+        for (int k = 0; k < 6; ++k) {   // the kernel times of pipelined Run()s accumulate until mpmvs_wait
+            c->k_ms[k] = 0.0f;
+            c->k_cnt[k] = 0;
+        }
+    c->async_outstanding++;
+    uint32_t launch = 0;
+    auto body = [&]() -> int {
+        int r;
+        if ((r = enqueue_step(c, p, seed, MPMVS_KIND_INIT, 0, p->max_scale, launch++))) return r;
+        if (p->geom_consistency || p->planar_prior) {
+            for (int i = 0; i < p->max_iterations; ++i) {
+                if ((r = enqueue_step(c, p, seed, MPMVS_KIND_BLACK, i, 0, launch++))) return r;
+                if ((r = enqueue_step(c, p, seed, MPMVS_KIND_RED, i, 0, launch++))) return r;
+            }
+        } else {
+            for (int s = p->max_scale; s >= 0; --s)
+                for (int i = 0; i < p->max_iterations; ++i) {
+                    if ((r = enqueue_step(c, p, seed, MPMVS_KIND_BLACK, i, s, launch++))) return r;
+                    if ((r = enqueue_step(c, p, seed, MPMVS_KIND_RED, i, s, launch++))) return r;
+                }
+        }
+        if ((r = enqueue_step(c, p, seed, MPMVS_KIND_DEPTH_NORMAL, 0, 0, launch++))) return r;
+        if ((r = enqueue_step(c, p, seed, MPMVS_KIND_FILTER_BLACK, 0, 0, launch++))) return r;
+        if ((r = enqueue_step(c, p, seed, MPMVS_KIND_FILTER_RED, 0, 0, launch++))) return r;
+        // the staging buffers are free once the previous call's copies have left them (a 0.7 ms copy against a whole Run())
+        if (c->async_outstanding > 1) HIPCHK(c, hipStreamWaitEvent(c->stream, c->staging_free, 0));
+        if (planes4) HIPCHK(c, hipMemcpyAsync(c->stage_planes, c->S.planes, wh * 16, hipMemcpyDeviceToDevice, c->stream));
+        if (costs) HIPCHK(c, hipMemcpyAsync(c->stage_costs, c->S.costs, wh * 4, hipMemcpyDeviceToDevice, c->stream));
+        if (geom) HIPCHK(c, hipMemcpyAsync(c->stage_geom, c->S.geom, wh * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(c->staged, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->staged, 0));
+        if (planes4) HIPCHK(c, hipMemcpyAsync(planes4, c->stage_planes, wh * 16, hipMemcpyDeviceToHost, c->copy_stream));
+        if (costs) HIPCHK(c, hipMemcpyAsync(costs, c->stage_costs, wh * 4, hipMemcpyDeviceToHost, c->copy_stream));
+        if (geom) HIPCHK(c, hipMemcpyAsync(geom, c->stage_geom, wh * 4, hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(c, hipEventRecord(c->staging_free, c->copy_stream));
+        return 0;
+    };
+    rc = body();
+    if (rc) {
+        c->async_outstanding = 0;
+        return abandon_run(c, rc);
+    }
+    return 0;
+}
+
+// Completes every pipelined Run() of the context: all result maps are in their host buffers when it returns.
+int mpmvs_wait(mpmvs_ctx* c) {
+    if (!c) return -1;
+    HIPCHK(c, enter_device(c->device));
+    c->async_outstanding = 0;
+    if (c->copy_stream && hipStreamSynchronize(c->copy_stream) != hipSuccess) {
+        c->err = "the device-to-host copies of a pipelined Run() failed";
+        return abandon_run(c, -100);
+    }
+    const int rc = finish(c);
+    return rc ? abandon_run(c, rc) : 0;
+}
+
+int mpmvs_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int kind, int iter, int scale, uint32_t launch_id) {
+    if (!c || !p) return -1;
+    ENTER(c);
     int rc = check_ready(c, p);
     if (rc) return rc;
     if ((rc = enqueue_step(c, p, seed, kind, iter, scale, launch_id)) || (rc = finish(c))) return abandon_run(c, rc);
@@ -1075,7 +1175,7 @@ int mpmvs_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int kind, int
 
 int mpmvs_get(mpmvs_ctx* c, void* planes4, void* costs, void* geom) {
     if (!c) return -1;
-    HIPCHK(c, enter_device(c->device));
+    ENTER(c);
     if (!c->S.planes) return fail(c, -1, "set_views first");
     const size_t wh = (size_t)c->W * c->H;
     if (planes4) HIPCHK(c, hipMemcpyAsync(planes4, c->S.planes, wh * 16, hipMemcpyDeviceToHost, c->stream));
@@ -1087,7 +1187,7 @@ int mpmvs_get(mpmvs_ctx* c, void* planes4, void* costs, void* geom) {
 
 int mpmvs_get_selected_views(mpmvs_ctx* c, void* sel) {
     if (!c) return -1;
-    HIPCHK(c, enter_device(c->device));
+    ENTER(c);
     if (!c->S.sel) return fail(c, -1, "set_views first");
     HIPCHK(c, hipMemcpyAsync(sel, c->S.sel, (size_t)c->W * c->H * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1096,7 +1196,7 @@ int mpmvs_get_selected_views(mpmvs_ctx* c, void* sel) {
 
 int mpmvs_export_depth_device(mpmvs_ctx* c, float* d_out) {
     if (!c) return -1;
-    HIPCHK(c, enter_device(c->device));
+    ENTER(c);
     if (!c->S.planes) return fail(c, -1, "set_views first");
     const int n = c->W * c->H;
     hipLaunchKernelGGL(k_export_depth, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S.planes, d_out, n);
@@ -1109,7 +1209,7 @@ int mpmvs_export_depth_device(mpmvs_ctx* c, float* d_out) {
 // adopted and removed again
 static int eval_ncc_impl(mpmvs_ctx* c, const mpmvs_params* p, const void* planes_cam4, int nh, int scale, int mapping, void* out, float* kernel_ms) {
     if (!c || !p) return -1;
-    HIPCHK(c, enter_device(c->device));
+    ENTER(c);
     int rc = check_ready(c, p);
     if (rc) return rc;
     if (scale < 0 || scale > 2) return fail(c, -3, "scale must be 0..2");
@@ -1170,7 +1270,7 @@ int mpmvs_eval_ncc_multi(mpmvs_ctx* c, const mpmvs_params* p, const void* planes
 
 int mpmvs_eval_geom(mpmvs_ctx* c, const mpmvs_params* p, const void* planes_cam4, void* out) {
     if (!c || !p) return -1;
-    HIPCHK(c, enter_device(c->device));
+    ENTER(c);
     if (c->n_img < 2) return fail(c, -1, "set_views first");
     if (!c->have_depths) return fail(c, -4, "need source depth maps");
     const size_t wh = (size_t)c->W * c->H;
@@ -1189,7 +1289,7 @@ int mpmvs_eval_geom(mpmvs_ctx* c, const mpmvs_params* p, const void* planes_cam4
 
 int mpmvs_homography(mpmvs_ctx* c, const void* plane4, int v, void* H9) {
     if (!c) return -1;
-    HIPCHK(c, enter_device(c->device));
+    ENTER(c);
     if (c->n_img < 2 || v < 0 || v >= c->hP.V) return fail(c, -1, "bad source view");
     DevBuf d_h;
     HIPCHK(c, d_h.alloc(9 * 4));
@@ -1206,7 +1306,7 @@ int mpmvs_homography(mpmvs_ctx* c, const void* plane4, int v, void* H9) {
 // ---------------------------------------------------------------------------
 int mpmvs_prior_vertices(mpmvs_ctx* c, int geom_rule, int* out_xy, int cap, int* n_out) {
     if (!c || !out_xy || cap < 0 || !n_out) return -1;
-    HIPCHK(c, enter_device(c->device));
+    ENTER(c);
     if (!c->S.costs) return fail(c, -1, "set_views first");
     const int W = c->W, H = c->H;
     const int ncx = (W + kPriorCell - 1) / kPriorCell, ncy = (H + kPriorCell - 1) / kPriorCell, ncells = ncx * ncy;
@@ -1237,7 +1337,7 @@ int mpmvs_prior_vertices(mpmvs_ctx* c, int geom_rule, int* out_xy, int cap, int*
 
 int mpmvs_prior_from_triangles(mpmvs_ctx* c, const mpmvs_params* p, const int* tri_xy, int n) {
     if (!c || !p || (n > 0 && !tri_xy) || n < 0) return -1;
-    HIPCHK(c, enter_device(c->device));
+    ENTER(c);
     if (!c->S.planes) return fail(c, -1, "set_views first");
     const int W = c->W, H = c->H;
     // vertex check and task table in one parallel sweep: 64 consecutive p-rows of one triangle per wave (pm_prior.hpp); a
@@ -1327,7 +1427,7 @@ int mpmvs_prior_from_triangles(mpmvs_ctx* c, const mpmvs_params* p, const int* t
 
 int mpmvs_get_prior(mpmvs_ctx* c, void* prior4, void* mask) {
     if (!c) return -1;
-    HIPCHK(c, enter_device(c->device));
+    ENTER(c);
     if (!c->have_prior) return fail(c, -5, "no prior installed");
     const size_t wh = (size_t)c->W * c->H;
     if (prior4) HIPCHK(c, hipMemcpyAsync(prior4, c->d_prior, wh * 16, hipMemcpyDeviceToHost, c->stream));

@@ -17,6 +17,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmpmvs_hip.so")
 _P = C.c_void_p
 _EXTRA = {
     "run_get": (C.c_int, [_P, C.POINTER(_abi.PatchMatchParams), C.c_uint64, _P, _P, _P]),
+    "run_get_async": (C.c_int, [_P, C.POINTER(_abi.PatchMatchParams), C.c_uint64, _P, _P, _P]),
+    "wait": (C.c_int, [_P]),
     "verify_rcp": (C.c_int, [C.POINTER(C.c_ulonglong)]),
     "device_count": (C.c_int, []),
     "set_src_depths_device": (C.c_int, [_P, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -82,6 +84,17 @@ class HipPatchMatch(_abi.PatchMatchHandle):
         assert planes.shape == (self.H, self.W, 4) and costs.shape == (self.H, self.W) and planes.dtype == np.float32 and costs.dtype == np.float32
         self._chk(self._f["run_get"](self._ctx, C.byref(params), int(seed), planes.ctypes.data, costs.ctypes.data,
                                      geom.ctypes.data if geom is not None else None), "run_get")
+
+    def run_into_async(self, params, seed, planes, costs, geom=None):
+        """pipelined Run() (mpmvs_run_get_async): returns at once; the maps reach the (pinned) arrays while the next such call
+        of this context already runs -- give consecutive calls different arrays and collect with wait()"""
+        assert planes.shape == (self.H, self.W, 4) and costs.shape == (self.H, self.W) and planes.dtype == np.float32 and costs.dtype == np.float32
+        self._chk(self._f["run_get_async"](self._ctx, C.byref(params), int(seed), planes.ctypes.data, costs.ctypes.data,
+                                           geom.ctypes.data if geom is not None else None), "run_get_async")
+
+    def wait(self):
+        """every pipelined Run() of this context has delivered its maps when this returns"""
+        self._chk(self._f["wait"](self._ctx), "wait")
 
     def set_texture_format(self, force_fp32):
         """call before set_views; True keeps the fp32 texture format even for 8-bit exact images"""

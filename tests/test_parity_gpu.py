@@ -75,6 +75,37 @@ def test_math_bit_exact(pm, oracle, engine, fn, lo, hi):
     assert_same(f"math fn {fn}", got, want)
 
 
+def test_pipelined_runs_equal_blocking_runs(pm, oracle, engine):
+    """mpmvs_run_get_async: four Run()s of one context back to back (different seeds, alternating host buffers, the last in
+    geometric mode) deliver what the blocking mpmvs_run_get delivers; between the first call and mpmvs_wait the context
+    refuses other entry points"""
+    import torch
+    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, 160, 120, 3)
+    H, W = 120, 160
+    rng = np.random.default_rng(3)
+    gpu.set_src_depths([sc.views[i].gt_depth * (1.0 + 0.01 * rng.standard_normal((H, W))).astype(np.float32) for i in (1, 2, 3)])
+    pg = pm.PatchMatchParams(num_images=4, depth_min=prm.depth_min, depth_max=prm.depth_max, max_scale=0, geom_consistency=True, max_iterations=2)
+    jobs = [(prm, SEED), (prm, SEED + 1), (prm, SEED + 2), (pg, SEED + 3)]
+    want = []
+    for p, s in jobs:
+        a, b, g = np.empty((H, W, 4), np.float32), np.empty((H, W), np.float32), np.empty((H, W), np.float32)
+        gpu.run_into(p, s, a, b, g)
+        want.append((a, b, g))
+    bufs = [tuple(torch.empty(shape, dtype=torch.float32, pin_memory=True).numpy() for shape in ((H, W, 4), (H, W), (H, W))) for _ in jobs]
+    for (p, s), (a, b, g) in zip(jobs, bufs):
+        gpu.run_into_async(p, s, a, b, g)
+    with pytest.raises(RuntimeError):
+        gpu.get()                       # -8: pipelined Run()s are in flight
+    gpu.wait()
+    for k, ((a, b, g), (wa, wb, wg)) in enumerate(zip(bufs, want)):
+        assert_same(f"planes of run {k}", a, wa)
+        assert_same(f"costs of run {k}", b, wb)
+        if jobs[k][0].geom_consistency:   # the photometric runs return whatever geometric map an earlier Run() left on the device
+            assert_same(f"geometric costs of run {k}", g, wg)
+    gp, gc = gpu.get()                  # the context is usable again and holds the last result
+    assert_same("state after wait", gp, want[-1][0])
+
+
 def test_run_get_equals_run_then_get(pm, oracle, engine):
     """mpmvs_run_get (Run() with its device-to-host copies, the cost maps overlapped with the median filter) returns what
     mpmvs_run + mpmvs_get return, in photometric and in geometric mode"""

@@ -1,7 +1,5 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r4g
-python -m pytest tests/test_parity_gpu.py tests/test_golden_gpu.py tests/test_fuzz_gpu.py tests/test_boundary_gpu.py -x -q > gpurun_out/r4g/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r4g/pytest.log
-python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary > /dev/null 2>&1
-
+mkdir -p gpurun_out/r4h
+python -m pytest tests/test_parity_gpu.py -x -q -k "pipelined or run_get" > gpurun_out/r4h/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r4h/pytest.log
 
