@@ -428,7 +428,9 @@ class RowPool {
     }
 };
 RowPool& row_pool() {
-    static RowPool p;
+    // deliberately leaked (never destroyed at process exit): in the child of a fork() the object names threads that do not exist
+    // there and its condition variable still counts the parent's waiters -- joining / destroying them blocks forever in exit()
+    static RowPool& p = *new RowPool;
     static const int registered = pthread_atfork(nullptr, nullptr, [] { RowPool::forked().store(true); });
     (void)registered;
     return p;
@@ -695,6 +697,16 @@ static int depth_slot(mpmvs_ctx* c, int i, int w, int h, bool replace) {
     return 0;
 }
 
+// A copy into a depth slot failed after depth_slot() may already have exchanged buffers: the device-side ProblemDev could still
+// name a buffer that went back to the pool.  The context then holds NO usable depth maps (a geometric Run() is refused by
+// check_ready until a later call succeeds) and nothing of this call is left in flight.
+static int depth_upload_failed(mpmvs_ctx* c) {
+    c->err = std::string("uploading a source depth map failed: ") + hipGetErrorString(hipGetLastError());
+    c->have_depths = false;
+    (void)hipStreamSynchronize(c->stream);
+    return -100;
+}
+
 int mpmvs_set_src_depths(mpmvs_ctx* c, int n_src, const float* const* depths, const int* widths, const int* heights, const size_t* pitch_bytes) {
     if (!c) return -1;
     ENTER(c);
@@ -715,7 +727,8 @@ int mpmvs_set_src_depths(mpmvs_ctx* c, int n_src, const float* const* depths, co
         const size_t pitch = pitch_bytes ? pitch_bytes[i] : (size_t)widths[i] * 4;
         ViewDev& o = c->hP.views[i];
         o.dw = widths[i], o.dh = heights[i];  // depth_slot compares against these
-        HIPCHK(c, hipMemcpy2DAsync(c->d_depth[i], (size_t)widths[i] * 4, depths[i], pitch, (size_t)widths[i] * 4, heights[i], hipMemcpyHostToDevice, c->stream));
+        if (hipMemcpy2DAsync(c->d_depth[i], (size_t)widths[i] * 4, depths[i], pitch, (size_t)widths[i] * 4, heights[i], hipMemcpyHostToDevice, c->stream) != hipSuccess)
+            return depth_upload_failed(c);
     }
     return attach_depths(c, n_src, widths, heights);
 }
@@ -738,7 +751,8 @@ int mpmvs_set_src_depths_device(mpmvs_ctx* c, int n_src, const float* const* d_d
             return rc;
         }
         c->hP.views[i].dw = widths[i], c->hP.views[i].dh = heights[i];
-        HIPCHK(c, hipMemcpyAsync(c->d_depth[i], d_depths[i], (size_t)widths[i] * heights[i] * 4, hipMemcpyDeviceToDevice, c->stream));
+        if (hipMemcpyAsync(c->d_depth[i], d_depths[i], (size_t)widths[i] * heights[i] * 4, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+            return depth_upload_failed(c);
     }
     return attach_depths(c, n_src, widths, heights);
 }
@@ -1005,9 +1019,6 @@ static int finish(mpmvs_ctx* c) {
 
 extern "C" {
 
-// Run() (ref .cu:1188-1254).  With output pointers the device-to-host copies that end the reference's Run() (:1246-1251) are
-// part of the call: costs (and geometric costs) are final after the last update launch, so they travel on a second stream
-// while GetDepthandNormal and the median filter still run; the planes follow on the main stream.
 // Everything a failed Run() may have left behind: launches and copies into caller buffers still in flight on either stream
 // (the caller may free its buffers once the call has returned), and profiling events that would otherwise be booked on the
 // next call.  Returns `rc` unchanged.

@@ -78,10 +78,13 @@ struct Triangle {
 //
 // `stamp` lets the device residency below recognise contents it already holds: 0 = unknown (every fresh image, and every
 // image written through at()); Seal() gives the present contents a unique stamp that travels with copies and moves.  Code
-// that writes `data` directly after sealing must reset the stamp.
+// that writes `data` directly after sealing should reset the stamp; as a safety net a sealed image also carries a fingerprint
+// of its contents (Fingerprint(): 4096 strided samples + the size), and an upload is only skipped while StillSealed() finds the
+// fingerprint unchanged -- a writer that forgot the stamp is then merely slower, not wrong (unless it changed none of the samples).
 struct Image {
     int rows = 0, cols = 0, ch = 1;
     uint64_t stamp = 0;
+    uint64_t sealed_fingerprint = 0;
     std::vector<float> data;
     Image() {}
     Image(int r, int c, int channels = 1, float v = 0.0f) : rows(r), cols(c), ch(channels), data((size_t)r * c * channels, v) {}
@@ -91,7 +94,10 @@ struct Image {
         return data[((size_t)r * cols + c) * ch + k];
     }
     float at(int r, int c, int k = 0) const { return data[((size_t)r * cols + c) * ch + k]; }
-    void Seal();  // the contents are final until the next write: a new unique stamp
+    void Seal();  // the contents are final until the next write: a new unique stamp (+ fingerprint)
+    void SealAs(uint64_t s);  // the same with a stamp shared by several maps (the results of one ProcessProblem)
+    uint64_t Fingerprint() const;
+    bool StillSealed() const { return stamp != 0 && sealed_fingerprint == Fingerprint(); }
 };
 uint64_t NewImageStamp();
 
@@ -221,6 +227,8 @@ class PatchMatchCUDA {
         return hostCosts.data();
     }
     float GetCost(const int index);
+    // the geometric-cost map of the last Run() that copied it (ref .cu:1248: only with params.geomPlanarPrior); zeros where the reference
+    // would return uninitialised memory (geometric mode without geomPlanarPrior)
     float GetGeomCost(const int index);
 
     float4 GetPriorPlaneParams(const Triangle triangle, int width);

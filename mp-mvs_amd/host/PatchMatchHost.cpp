@@ -80,7 +80,34 @@ uint64_t NewImageStamp() {
     static std::atomic<uint64_t> next(1);
     return next.fetch_add(1);
 }
-void Image::Seal() { stamp = NewImageStamp(); }
+void Image::Seal() { SealAs(NewImageStamp()); }
+void Image::SealAs(uint64_t s) {
+    stamp = s;
+    sealed_fingerprint = Fingerprint();
+}
+// FNV-1a over the bit patterns of up to 4096 evenly strided samples, the first and the last element and the shape
+uint64_t Image::Fingerprint() const {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&h](uint64_t v) {
+        h ^= v;
+        h *= 1099511628211ull;
+    };
+    mix((uint64_t)rows);
+    mix((uint64_t)cols);
+    mix((uint64_t)ch);
+    const size_t n = data.size();
+    if (n == 0) return h;
+    const size_t step = n > 4096 ? n / 4096 : 1;
+    for (size_t i = 0; i < n; i += step) {
+        uint32_t b;
+        std::memcpy(&b, &data[i], 4);
+        mix(b);
+    }
+    uint32_t b;
+    std::memcpy(&b, &data[n - 1], 4);
+    mix(b);
+    return h;
+}
 void ReleaseDeviceCaches(std::vector<Scene>& Scenes) {
     for (Scene& s : Scenes) s.device_cache.reset();
 }
@@ -217,7 +244,12 @@ void PatchMatchCUDA::AllocatePatchMatch() {
     // not zero-filled (the reference's new[] is not either): Run() and CudaMemInit write them in full before anything reads
     hostPlaneHypotheses.allocate(wh);
     hostCosts.allocate(wh);
-    if (params.geom_consistency) hostGeomCosts.allocate(wh);
+    if (params.geom_consistency) {
+        hostGeomCosts.allocate(wh);
+        // Run() fills it only when params.geomPlanarPrior is set (ref .cu:1248): otherwise GetGeomCost() would hand out whatever
+        // the recycled page-locked block held before (the reference returns uninitialised new[] memory there): zeros instead
+        if (!params.geomPlanarPrior) std::memset(hostGeomCosts.data(), 0, wh * sizeof(float));
+    }
 }
 
 // reference src/PatchMatch.cpp:998-1089
@@ -244,7 +276,7 @@ void PatchMatchCUDA::CudaMemInit(Scene& scene) {
         if (resident_depth_stamps.size() != depths.size()) resident_depth_stamps.assign(depths.size(), 0);
         bool any = false;
         for (size_t i = 0; i < depths.size(); ++i) {
-            if (depths[i]->stamp != 0 && depths[i]->stamp == resident_depth_stamps[i])
+            if (depths[i]->stamp != 0 && depths[i]->stamp == resident_depth_stamps[i] && depths[i]->StillSealed())
                 dptr[i] = nullptr;
             else
                 any = true;
@@ -259,7 +291,8 @@ void PatchMatchCUDA::CudaMemInit(Scene& scene) {
         // ... unless the adopted context still holds exactly that state: the maps carry the stamp ProcessProblem gave its
         // results when it left the context behind
         const bool state_resident = resident_state_stamp != 0 && scene.depth.stamp == resident_state_stamp &&
-                                    scene.normal.stamp == resident_state_stamp && scene.cost.stamp == resident_state_stamp;
+                                    scene.normal.stamp == resident_state_stamp && scene.cost.stamp == resident_state_stamp &&
+                                    scene.depth.StillSealed() && scene.normal.StillSealed() && scene.cost.StillSealed();
         if (!state_resident) {
             const Image &sn = scene.normal, &sd = scene.depth, &sc = scene.cost;
             const int width = sd.cols, height = sd.rows;
@@ -520,7 +553,9 @@ void ProcessProblem(std::vector<Scene>& Scenes, const int ID, bool geom_consiste
     // the three maps are exactly what the context holds now: one stamp for them and for the context that Release() leaves
     // with the Scene, so that the next pass over this Problem finds its start state in HBM
     const uint64_t stamp = NewImageStamp();
-    out.depth.stamp = out.normal.stamp = out.cost.stamp = stamp;
+    out.depth.SealAs(stamp);
+    out.normal.SealAs(stamp);
+    out.cost.SealAs(stamp);
     MP.NoteResidentState(stamp);
     if (!results) {
         scene.depth = std::move(out.depth);
@@ -608,6 +643,16 @@ int mpmvs_host_prior_from_triangles(const mpmvs_camera* cam, int w, int h, const
 }
 
 // bilinear resize probe (ResizeLinear)
+// test hook of the residency safety net (Image::StillSealed): seal a rows x cols map, then overwrite `n_writes` elements
+// starting at `first` DIRECTLY in `data` (a writer that forgot to reset the stamp); returns 1 if the map still counts as sealed
+int mpmvs_host_test_seal(const float* src, int rows, int cols, long first, long n_writes, float value) {
+    Image im(rows, cols);
+    std::memcpy(im.data.data(), src, im.data.size() * sizeof(float));
+    im.Seal();
+    for (long i = 0; i < n_writes && first + i < (long)im.data.size(); ++i) im.data[first + i] = value;
+    return im.StillSealed() ? 1 : 0;
+}
+
 int mpmvs_host_resize_linear(const float* src, int w, int h, float* dst, int new_w, int new_h) {
     Image s(h, w, 1);
     std::memcpy(s.data.data(), src, s.data.size() * sizeof(float));

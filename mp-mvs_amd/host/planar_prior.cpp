@@ -33,6 +33,7 @@
 #include <mutex>
 #include <memory>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "PatchMatch.h"
@@ -164,6 +165,9 @@ typedef __int128 i128;
 // with explicit placement the 15 thread creations and migrations of a call cost more than the triangulation itself:
 // 22 ms on 16 threads against 60 ms on one.)  One call at a time uses the pool; a caller that finds it busy -- several
 // Problems triangulate at once in the multi-Problem schedule -- runs its triangulation on its own thread instead.
+// set in the child of a fork(): the pool object is inherited, its threads are not
+static std::atomic<bool> g_pool_forked(false);
+
 class HostPool {
     std::vector<std::thread> workers;
     std::mutex mu;
@@ -211,8 +215,15 @@ class HostPool {
             for (int i = 0; i < CPU_SETSIZE; ++i)
                 if (CPU_ISSET(i, &set)) cpus.push_back(i);
         // slot 0 is the caller's place: the workers take the CPUs after it, spread over the mask (SMT siblings are usually
-        // numbered half the mask apart, so neighbours in the list are distinct cores)
-        for (int t = 1; t < threads; ++t) workers.emplace_back(&HostPool::worker, this, t, cpus);
+        // numbered half the mask apart, so neighbours in the list are distinct cores).  Several processes of one box (one rank
+        // per GPU) share the mask: each starts at its own stretch of it -- LOCAL_RANK x pool size, or a stretch picked by the
+        // process id -- instead of all pinning onto the same CPUs.
+        int base = 0;
+        if (!cpus.empty()) {
+            const char* lr = std::getenv("LOCAL_RANK");
+            base = (int)(((lr ? (long)std::atoi(lr) : (long)(getpid() % 64)) * threads) % (long)cpus.size());
+        }
+        for (int t = 1; t < threads; ++t) workers.emplace_back(&HostPool::worker, this, base + t, cpus);
     }
     ~HostPool() {
         {
@@ -257,22 +268,25 @@ int HostThreads() {
 // it.  It is rebuilt when MPMVS_HOST_THREADS asks for another size than it has (tests walk through thread counts).
 HostPool* AcquireSharedPool() {
     static std::mutex mu;
-    static std::unique_ptr<HostPool> pool;
+    // never destroyed at process exit (a raw pointer, deliberately leaked): in the child of a fork() the object names threads
+    // that do not exist there and its condition variable still counts the parent's waiters -- joining the one or destroying the
+    // other blocks forever in exit().  Only a change of MPMVS_HOST_THREADS deletes a pool (in the process that built it).
+    static HostPool* pool = nullptr;
     // a forked child inherits the pool object but not its threads: it triangulates on its own thread
-    static std::atomic<bool> forked(false);
-    static const int registered = pthread_atfork(nullptr, nullptr, [] { forked.store(true); });
+    static const int registered = pthread_atfork(nullptr, nullptr, [] { g_pool_forked.store(true); });
     (void)registered;
-    if (forked.load(std::memory_order_relaxed)) return nullptr;
+    if (g_pool_forked.load(std::memory_order_relaxed)) return nullptr;
     std::lock_guard<std::mutex> lk(mu);
     const int want = HostThreads();
     if (want < 2) return nullptr;
-    if (pool && pool->size() == want) return pool->try_acquire() ? pool.get() : nullptr;
+    if (pool && pool->size() == want) return pool->try_acquire() ? pool : nullptr;
     if (pool) {
         if (!pool->try_acquire()) return nullptr;  // in use at its old size: this caller runs on its own thread
         pool->release();
+        delete pool;
     }
-    pool.reset(new HostPool(want));
-    return pool->try_acquire() ? pool.get() : nullptr;
+    pool = new HostPool(want);
+    return pool->try_acquire() ? pool : nullptr;
 }
 
 struct Zipper {

@@ -481,9 +481,11 @@ def test_unassigned_cell_points_are_pixel_zero(hostlib):
     assert hostlib.triangulate_vertices(costs, geom, True).tolist() == [[0, 0], [0, 0], [0, 0], [8, 7]]
 
 
-def test_delaunay_in_a_forked_child(hostlib):
+@pytest.mark.parametrize("leave", ["_exit", "exit"])
+def test_delaunay_in_a_forked_child(hostlib, leave):
     """the persistent thread pool of the triangulation does not survive a fork: the child must notice and run on its own
-    thread instead of waiting for workers it does not have"""
+    thread instead of waiting for workers it does not have -- and, when it leaves through exit(), the static destructors of the
+    pools must not join threads that do not exist in the child"""
     rng = np.random.default_rng(0)
     pts = rng.integers(0, 2000, size=(9000, 2)).astype(np.int32)
     ref = np.array(hostlib.delaunay(2000, 2000, pts))           # creates the pool in this process
@@ -493,6 +495,9 @@ def test_delaunay_in_a_forked_child(hostlib):
             ok = np.array_equal(ref, np.array(hostlib.delaunay(2000, 2000, pts)))
         except BaseException:
             ok = False
+        if leave == "exit" and ok:
+            import ctypes
+            ctypes.CDLL(None).exit(0)      # libc exit(): runs the static destructors of the loaded libraries
         os._exit(0 if ok else 3)
     deadline = 60.0
     import time
@@ -528,3 +533,19 @@ def test_delaunay_large_sets_agree_across_thread_counts(hostlib, monkeypatch, ki
             assert len(tris) <= 2 * len(uniq) and len(tris) >= len(uniq)
         else:
             assert np.array_equal(ref, tris), f"{threads} threads"
+
+
+def test_sealed_map_notices_a_direct_write(hostlib):
+    """The C++ mirror skips the upload of a source depth map / start state the resident context already holds (Image::stamp).  A
+    writer that changes `data` directly and forgets the stamp must not make it skip a CHANGED map: a sealed image carries a
+    fingerprint of its contents (4096 strided samples), and the skip requires it unchanged."""
+    import ctypes as C
+    lib = hostlib.load()
+    lib.mpmvs_host_test_seal.restype = C.c_int
+    lib.mpmvs_host_test_seal.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_long, C.c_float]
+    rng = np.random.default_rng(0)
+    a = rng.uniform(1, 9, (1200, 1600)).astype(np.float32)
+    assert lib.mpmvs_host_test_seal(a.ctypes.data, 1200, 1600, 0, 0, 0.0) == 1                 # untouched: still sealed
+    assert lib.mpmvs_host_test_seal(a.ctypes.data, 1200, 1600, 0, a.size, 3.0) == 0            # a whole new map
+    assert lib.mpmvs_host_test_seal(a.ctypes.data, 1200, 1600, 600 * 1600, 40 * 1600, 3.0) == 0  # a band of rows
+    assert lib.mpmvs_host_test_seal(a.ctypes.data, 1200, 1600, a.size - 1, 1, 3.0) == 0        # the last element
