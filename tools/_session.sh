@@ -1,13 +1,6 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r4i
-python bench.py > gpurun_out/r4i/bench.json 2> gpurun_out/r4i/bench.err; echo "bench rc=$?"
-bash tools/profile_gpu.sh r04z > gpurun_out/r4i/profile.log 2>&1; echo "profile rc=$?"
-bash tools/trace_kernels.sh r04 bench.py --steps 5 --warmup 1 --no-secondary --no-cpu-baseline > gpurun_out/r4i/trace.log 2>&1
-python bench.py --no-secondary --no-cpu-baseline > gpurun_out/r4i/bench_after_profile.json 2>/dev/null
-python tools/bench_scales.py > gpurun_out/r4i/scales.json 2>/dev/null
-python tools/bench_views.py > gpurun_out/r4i/views.txt 2>/dev/null
-python tools/bench_modes_step.py > gpurun_out/r4i/modes_step.json 2>/dev/null
-python tools/bench_launches.py > gpurun_out/r4i/launches.json 2>/dev/null
-python tools/kernel_resources.py > gpurun_out/r4i/kernel_resources.txt 2>&1
-echo done
+mkdir -p gpurun_out/r4j
+python -m pytest tests/test_parity_gpu.py tests/test_golden_gpu.py tests/test_fuzz_gpu.py -x -q > gpurun_out/r4j/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r4j/pytest.log
+python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary > /dev/null 2>&1
+bash tools/trace_kernels.sh f1 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary | head -8
