@@ -174,6 +174,13 @@ def test_geom_cost_canonical_vs_literal(pm, oracle):
     W, H, V = 200, 150, 4
     sc = pm.synth.make_problem_scene(W, H, n_src=V, spacing=0.3, rot_deg=3.0, focal_jitter=0.05)
     cams, imgs = sc.problem(0, list(range(1, V + 1)))
+    import copy
+    cams = [copy.copy(c) for c in cams]
+    for i, c in enumerate(cams):
+        # a full K: skew and a small off-diagonal term -- ProjectPoint uses all nine entries (ref .cu:612-614), BackProjectPoint2W
+        # only fx, fy, cx, cy (:587-589); the composed maps must treat each camera the same two ways
+        c.K[1] = 0.7 + 0.1 * i
+        c.K[3] = 0.02 * (i + 1)
     h = oracle.create()
     h.set_views(cams, imgs)
     dmin, dmax = pm.synth.kernel_depth_range(cams[0])

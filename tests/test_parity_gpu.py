@@ -215,6 +215,40 @@ def test_geom_cost_bit_exact(pm, oracle, engine):
     assert got.max() <= 3.0 and (got < 3.0).mean() > 0.05
 
 
+def test_geom_cost_full_intrinsics_and_sizes_bit_exact(pm, oracle, engine):
+    """the composed maps of the geometric check are formed on the host of BOTH implementations from the cameras:
+    per-view intrinsics with skew and off-diagonal terms (ProjectPoint uses all of K, BackProjectPoint2W only fx, fy, cx, cy),
+    t and C given independently, depth maps of another size than the images, a full geometric Run() on top"""
+    import copy
+    W, H, V = 112, 80, 4
+    sc = pm.synth.make_problem_scene(W, H, n_src=V, spacing=0.4, rot_deg=3.0, focal_jitter=0.05, quantize=True)
+    cams, imgs = sc.problem(0, list(range(1, V + 1)))
+    cams = [copy.copy(c) for c in cams]
+    for i, c in enumerate(cams):
+        c.K[1] = 0.5 + 0.2 * i
+        c.K[3] = 0.01 * (i + 1)
+        c.C[0] += 1e-4 * i          # C no longer exactly -R^T t: each is used where the reference uses it
+    gpu, cpu = engine.create(0), oracle.create()
+    dmin, dmax = pm.synth.kernel_depth_range(cams[0])
+    prm = pm.PatchMatchParams(num_images=V + 1, depth_min=float(dmin), depth_max=float(dmax), max_scale=0)
+    rng = np.random.default_rng(9)
+    depths = []
+    for i in range(1, V + 1):
+        d = sc.views[i].gt_depth * (1.0 + 0.005 * rng.standard_normal((H, W))).astype(np.float32)
+        depths.append(np.ascontiguousarray(d[:H - 6 * (i % 2), :W - 10 * (i % 3)]))   # clamped fetch against the MAP's size
+    for h in (gpu, cpu):
+        h.set_views(cams, imgs)
+        h.set_src_depths(depths)
+    planes = random_planes(pm, cams[0], W, H, rng, prm.depth_min, prm.depth_max)
+    assert_same("geom cost", gpu.eval_geom(prm, planes), cpu.eval_geom(prm, planes))
+    for h in (gpu, cpu):
+        h.run(prm, SEED)
+    prm.geom_consistency, prm.max_iterations = True, 2
+    for h in (gpu, cpu):
+        h.run(prm, SEED + 1)
+    compare_state(gpu, cpu, "geometric run, full K", geom=True)
+
+
 # ---------------------------------------------------------------------------
 # T2: single kernels from identical state, all three modes
 # ---------------------------------------------------------------------------
