@@ -51,6 +51,7 @@ class SceneScheduler:
             assert im.shape == (self.H, self.W), "the all-gather assumes equally sized depth maps"
         self.device_tensors = device_tensors
         self.fetch_results = True   # device mode only: False leaves every pass's maps in HBM (bench.py --workload cfg4)
+        self.force_collective = False   # tests: issue the all-gather also with a single rank (RCCL's one-rank path on one GPU)
         self.handles = {}
         for i in self.owned:
             h = make_handle()
@@ -145,7 +146,7 @@ class SceneScheduler:
             torch.cuda.current_stream().synchronize()     # (1)
             for k, i in enumerate(self.owned):
                 self.handles[i].export_depth_device(mine[k].data_ptr())   # (2)
-            if self.world > 1:
+            if self.world > 1 or (self.force_collective and self.dist is not None):
                 full = torch.empty((self.world * self.per_rank, self.H, self.W), dtype=torch.float32, device="cuda")
                 self.dist.all_gather_into_tensor(full, mine)
             else:

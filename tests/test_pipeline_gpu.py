@@ -318,3 +318,35 @@ def test_bench_self_launched_two_ranks_share_the_gpu():
     assert c4["n_gpus"] == 2 and c4["scaling"] == "strong" and c4["config"]["problems"] == 9
     assert [p["pass"] for p in c4["passes_last_step"]] == ["photometric", "geometric + planar prior", "geometric"]
     assert all(p["exchange_ms"] >= 0 for p in c4["passes_last_step"]) and c4["within_1pct_of_gt_rank0_mean"] > 0.6   # 160x120 views: coarser than the cfg-1 check above
+
+
+def test_scheduler_exchange_through_rccl_single_rank(pm, engine):
+    """The exchange's collective on the real device: torch.distributed with the nccl backend (= RCCL) and ONE rank -- all this pool's
+    1-GPU boxes allow -- issues all_gather_into_tensor on the gathered device buffer between the passes (RCCL's stream against the
+    contexts' own streams: the ordering of schedule.py:_exchange).  Same bits as the run without the collective."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    sched = importlib.import_module("mp-mvs_amd.schedule")
+    sc, neigh = pm.synth.make_grid_scene(96, 64, 3, 2, spacing=0.5, rot_deg=1.0, quantize=True)
+    cams = [v.cam for v in sc.views]
+    imgs = [v.image for v in sc.views]
+    kw = dict(geom_iterations=2, planar_prior=True, geom_planar_prior=True, seed=99)
+    plain = sched.SceneScheduler(cams, imgs, neigh, lambda: engine.create(0), device_tensors=True, max_scale=1)
+    want = plain.run(**kw)
+    want_depths = plain.depth_maps()
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        coll = sched.SceneScheduler(cams, imgs, neigh, lambda: engine.create(0), rank=0, world=1, dist=dist, device_tensors=True, max_scale=1, workers=2)
+        coll.force_collective = True
+        got = coll.run(**kw)
+        assert np.array_equal(coll.depth_maps(), want_depths)
+        for i in range(6):
+            assert np.array_equal(got[i][0], want[i][0]) and np.array_equal(got[i][1], want[i][1]), f"problem {i}"
+    finally:
+        dist.destroy_process_group()

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_parity_gpu.py -x -q -k "geom" 2>&1 | tail -4
+timeout -k 10 300 python -m pytest tests/test_pipeline_gpu.py -x -q -k "rccl" 2>&1 | tail -8
