@@ -85,8 +85,8 @@ def load_views(pm, w, h, centers, tag, rank=0, world=1, barrier=None):
                 tmp = paths[i] + f".{os.getpid()}.tmp.npz"
                 np.savez(tmp, img=v.image, gt=v.gt_depth, cam=_cam_bytes(v.cam))
                 os.replace(tmp, paths[i])
-        if barrier is not None:
-            barrier()
+    if barrier is not None:
+        barrier()   # unconditional: a rank that finds the cache complete must still meet the ranks that are filling it
     cams, imgs, gts = [], [], []
     for p in paths:
         z = np.load(p)
