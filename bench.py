@@ -564,6 +564,9 @@ def main():
     ap.add_argument("--size", default=None, help="WxH of the cfg-1 Problem instead of 1600x1200 (tests of the multi-rank plumbing; the line says so)")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--child-seed", type=int, default=12345, help=argparse.SUPPRESS)
+    ap.add_argument("--no-overlap-phase", action="store_true",
+                    help="skip the untimed two-context pipeline (value_survey_8d_pipelined): its kernels overlap, which inflates the per-kernel "
+                         "durations of a kernel trace of this command (tools/profile_gpu.sh, tools/trace_kernels.sh use it)")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--launch-check-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -673,21 +676,23 @@ def main():
     # ... and the same as a pipeline over TWO contexts, the way a job with many Problems runs ("several Problems resident
     # per GPU"): Problem i + 1 is converted, uploaded and packed on its own context and stream while Problem i computes, and the
     # maps of Problem i travel back while Problem i + 1 computes.  Every upload and every map is complete inside the timed region.
-    ctx_b = engine.create(dev_index)
-    ctx_b.set_views(cams, imgs)      # untimed: allocations of the second context
-    pair = ((ctx, bufs), (ctx_b, bufs2))
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        c_i, b_i = pair[i % 2]
-        c_i.wait()                   # its previous Run() has delivered: textures and host buffers are free again
-        c_i.set_views(cams, imgs)
-        c_i.run_into_async(prm, seed + i, *b_i)
-    ctx.wait()
-    ctx_b.wait()
-    barrier()
-    dt_h2d_pipe = time.perf_counter() - t0
-    del ctx_b
+    dt_h2d_pipe = float("nan")
+    if not args.no_overlap_phase:
+        ctx_b = engine.create(dev_index)
+        ctx_b.set_views(cams, imgs)      # untimed: allocations of the second context
+        pair = ((ctx, bufs), (ctx_b, bufs2))
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            c_i, b_i = pair[i % 2]
+            c_i.wait()                   # its previous Run() has delivered: textures and host buffers are free again
+            c_i.set_views(cams, imgs)
+            c_i.run_into_async(prm, seed + i, *b_i)
+        ctx.wait()
+        ctx_b.wait()
+        barrier()
+        dt_h2d_pipe = time.perf_counter() - t0
+        del ctx_b
     if dist is not None:
         t = torch.tensor([dt_res, dt_h2d, dt_blocking, dt_h2d_pipe], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -736,7 +741,7 @@ def main():
             "value_survey_8d": round(world * W * H * args.steps / dt_h2d / 1e6, 3),
             "value_survey_8d_is": "SURVEY 8(d)'s wording of the metric: image upload (host 8-bit conversion, H2D, texture packing) + Run() + D2H per step, "
                                   f"{args.steps} steps one after the other on one context, between the same barriers as `value`; `value` itself keeps the inputs resident (bench contract)",
-            "value_survey_8d_pipelined": round(world * W * H * args.steps / dt_h2d_pipe / 1e6, 3),
+            "value_survey_8d_pipelined": None if args.no_overlap_phase else round(world * W * H * args.steps / dt_h2d_pipe / 1e6, 3),
             "value_survey_8d_pipelined_is": "the same work -- every step uploads its 9 images, runs and returns its maps inside the timed region -- as a pipeline over two contexts "
                                             "(Problem i + 1 is uploaded and Problem i - 1 downloaded while Problem i computes): what a job with many Problems gets",
             "roofline": {

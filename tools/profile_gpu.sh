@@ -10,7 +10,7 @@ TAG=${1:-r1}
 shift
 # default: the command whose line the driver records, minus the untimed extras -- so that the trace average of k_update is
 # comparable with the HIP-event average of the plain run (bench.py quotes the counters only if the two agree within 3 %)
-if [ $# -eq 0 ]; then set -- bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary; fi
+if [ $# -eq 0 ]; then set -- bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary --no-overlap-phase; fi
 cd ${GRAFT_REPO_ROOT:?}
 export OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
