@@ -113,23 +113,19 @@ def load_scene(pm, w, h, v, quantize):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-KERNEL_SOURCES = ("mp-mvs_amd/csrc/pm_kernels.hpp", "mp-mvs_amd/csrc/pm_device.hpp", "mp-mvs_amd/csrc/mpmvs_api.hip", "mp-mvs_amd/csrc/Makefile")
-
-
-def kernel_sources_sha256():
-    """identifies the kernel build a profile belongs to (tools/summarize_prof.py writes the same hash into its summary)"""
+def kernel_build_sha256():
+    """identifies the kernel BUILD a profile belongs to: the hash of the HIP library that is loaded (the build is deterministic, and a
+    comment-only edit of the sources gives the same binary); tools/summarize_prof.py writes the same hash into its summary"""
     import hashlib
-    h = hashlib.sha256()
-    for rel in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, rel), "rb") as f:
-            h.update(f.read())
-    return h.hexdigest()[:16]
+    path = os.environ.get("MPMVS_HIP_LIB", os.path.join(ROOT, "mp-mvs_amd", "csrc", "libmpmvs_hip.so"))
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 def profile_counters(upd_avg_ms):
     """PMC figures of k_update from the latest committed `profiles/*pmc_summary*` file (rocprofv3 --pmc passes of this same
     command, tools/profile_gpu.sh: PMC cannot be read in-process) -- but only if that profile describes THIS build and THIS
-    run: its recorded kernel-source hash must equal the tree's and its kernel-trace average of k_update must lie within 3 % of
+    run: its recorded hash of the HIP library must equal that of the library in use and its kernel-trace average of k_update must lie within 3 % of
     the average this run measured with HIP events.  Otherwise every figure is None and `reason` says why.
     FETCH_SIZE / WRITE_SIZE are KiB at the L2's memory side.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 128-byte
     requests at 64 bytes (exactly half for wide coalesced streaming reads), other access widths are uncalibrated: this kernel's
@@ -154,8 +150,8 @@ def profile_counters(upd_avg_ms):
         elif kern == "k_update" and "avg=" in t:
             vals[t.split()[0]] = float(t.split("avg=")[1])
     src = f"profiles/{name}"
-    if meta.get("kernel_sources_sha256") != kernel_sources_sha256():
-        return dict(none, source=src, reason=f"{src} was collected on another kernel build (sources hash {meta.get('kernel_sources_sha256')} != {kernel_sources_sha256()})")
+    if meta.get("kernel_build_sha256") != kernel_build_sha256():
+        return dict(none, source=src, reason=f"{src} was collected on another kernel build (library hash {meta.get('kernel_build_sha256')} != {kernel_build_sha256()})")
     if trace_avg is None or abs(trace_avg - upd_avg_ms) > 0.03 * upd_avg_ms:
         return dict(none, source=src, reason=f"{src}: k_update averaged {trace_avg} ms there, {upd_avg_ms:.4f} ms in this run (more than 3 % apart)")
     out = dict(none, source=src + f" (git {meta.get('git_head', '?')}, k_update trace average {trace_avg} ms; command: {meta.get('command', '?')})")

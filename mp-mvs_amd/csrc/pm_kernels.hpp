@@ -5,7 +5,8 @@
 // weight records of the pixel's window live in LDS (written once per pixel and launch, read by every evaluation).
 // k_update walks its 14 hypotheses in two phases, each VIEW BY VIEW (the eight propagated candidates of a view back to back,
 // then the current plane, then the five refinement candidates of a view back to back), through inlined copies of the
-// unrolled 36-tap NCC loop (ncc_core, pm_device.hpp) -- five copies in the photometric kernel's ISA.
+// unrolled 36-tap NCC loop (ncc_core, pm_device.hpp) -- four copies in the photometric kernel's ISA (58 KB of code; the
+// instruction cache misses 2.6 k times in 293 M fetches per launch: profiles/r04_scratch_and_icache_bound.txt).
 // MFMA is not used: there is no dense contraction on this path.
 #pragma once
 
@@ -225,7 +226,8 @@ PM_DEV float prior_term_body(float depth_diff, float angle_cos, float two_ds2, f
     const float ad = d_acos(angle_cos);
     return 0.5f + d_exp(-depth_diff * depth_diff / two_ds2) * d_exp(-ad * ad / two_as2);
 }
-// as a real call for the many-view variants of the update kernel (register pressure, see geom_cost_view)
+// as a real call for the many-view variants of the update kernel: inlined three times next to the unrolled NCC loops it pushed
+// the variants above 8 views into hundreds of spilled registers
 __device__ __attribute__((noinline)) float prior_term_call(float depth_diff, float angle_cos, float two_ds2, float two_as2) {
     return prior_term_body(depth_diff, angle_cos, two_ds2, two_as2);
 }

@@ -14,9 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 try:
     import bench
-    print(f"# kernel_sources_sha256: {bench.kernel_sources_sha256()}")
+    print(f"# kernel_build_sha256: {bench.kernel_build_sha256()}")
 except Exception as e:  # noqa: BLE001
-    print(f"# kernel_sources_sha256: unavailable ({e})")
+    print(f"# kernel_build_sha256: unavailable ({e})")
 for key, path in (("command", os.path.join(out, "command.txt")), ("git_head", os.path.join(ROOT, "build", "git_head.txt"))):
     if os.path.exists(path):
         print(f"# {key}: {open(path).read().strip()}")
