@@ -389,6 +389,22 @@ def secondary(pm, engine, dev_index, cams, imgs_f32, gts, prm, args):
                                  "resident_Mpix_per_s": round(W * H * 5 / dt / 1e6, 3), "k_update_avg_ms": round(upd_ms / upd_n, 4),
                                  "roofline_frac": round(tf / PEAK_VALU_TFLOPS, 4)}
     del ctx
+    # -- cfg 1 on the opt-in build with CUDA's 8-bit texture interpolation fractions (libmpmvs_hip_q8.so)
+    try:
+        ctx = engine.create_q8(dev_index)
+        ctx.set_views(cams, imgs_u8)
+        ctx.set_profiling(True)
+        ctx.run(prm, 1)
+        dt, upd_ms, upd_n, _ = timed_runs(pm, ctx, prm, 100, 5)
+        _, tf = roofline_of(upd_ms / upd_n, W, H, V)
+        planes, _ = ctx.get()
+        rel = np.abs(planes[..., 3] - gt) / gt
+        out["cfg1_8bit_texture_fractions"] = {"workload": "configs[1] on libmpmvs_hip_q8.so: bilinear fractions quantised to 8 bits like the reference's texture hardware (opt-in)",
+                                              "resident_Mpix_per_s": round(W * H * 5 / dt / 1e6, 3), "k_update_avg_ms": round(upd_ms / upd_n, 4),
+                                              "roofline_frac": round(tf / PEAK_VALU_TFLOPS, 4), "within_1pct_of_gt": round(float((rel < 0.01).mean()), 4)}
+        del ctx
+    except RuntimeError as e:
+        out["cfg1_8bit_texture_fractions"] = {"error": str(e)}
     # -- cfg 1 with 20 source views (the shipped `Max source images num`, config/config.yaml:19) at 800x600
     w2, h2, v2 = 800, 600, 20
     cams20, imgs20, gts20 = load_views(pm, w2, h2, problem_centers(pm, v2), f"p{v2}")

@@ -82,6 +82,10 @@ enum {
 /* number of visible HIP devices (replaces the hard-coded cudaSetDevice(0),
  * src/PatchMatch.cpp:509) */
 int mpmvs_device_count(void);
+/* Which build of the library this is: 0 = bilinear interpolation with exact fp32 fractions (libmpmvs_hip.so, the default), 8 = the
+ * fractions quantised to 8 bits as CUDA's texture unit does for the reference's tex2D fetches (reference src/PatchMatch.cu:377;
+ * libmpmvs_hip_q8.so, opt-in: closer to the reference BINARY by the last digit of north_star's 1e-3, slower per tap). */
+int mpmvs_texture_filter_bits(void);
 
 /* PatchMatchCUDA construction + AllocatePatchMatch (src/PatchMatch.cpp:516,960-976) */
 mpmvs_ctx* mpmvs_create(int device);

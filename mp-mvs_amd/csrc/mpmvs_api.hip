@@ -513,6 +513,14 @@ static void stage_images(int n, const mpmvs_camera* cams, const float* const* im
 
 extern "C" {
 
+int mpmvs_texture_filter_bits(void) {
+#ifdef PM_TEX_Q8
+    return 8;
+#else
+    return 0;
+#endif
+}
+
 int mpmvs_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

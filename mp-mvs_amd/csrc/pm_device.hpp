@@ -528,6 +528,17 @@ PM_DEV SrcTex8 make_src_tex8(const ViewDev& vw) {
     return t;
 }
 
+// Opt-in build -DPM_TEX_Q8 (libmpmvs_hip_q8.so): the interpolation fractions are quantised to 8 bits the way CUDA's texture unit does
+// it (frac = floor(a * 256 + 0.5) / 256; CUDA C Programming Guide, "Linear Filtering": 9-bit fixed point with 8 bits of fraction) --
+// what the reference's tex2D fetches apply on its hardware (ref .cu:377).  The default build keeps exact fp32 fractions: against the
+// reference's FORMULAS it is within north_star's 1e-3, against formulas + this quantisation the tail reaches 1.9e-3;
+// the q8 build closes that last digit for +6 instructions per tap.
+#ifdef PM_TEX_Q8
+PM_DEV float tex_fraction(float a) { return __builtin_floorf(__builtin_fmaf(a, 256.0f, 0.5f)) * 0.00390625f; }
+#else
+PM_DEV float tex_fraction(float a) { return a; }
+#endif
+
 // Bilinear tap in two halves: issue() clamps the coordinate, computes the address and starts the load; value()
 // interpolates (ref .cu:377: tex2D(t, x+0.5, y+0.5) with the linear filter, software here: SURVEY a-2).  Lets a whole
 // window column be in flight at once.
@@ -542,8 +553,8 @@ struct BilinearTap<false> {
     PM_DEV void issue(const TEX& t, float sx, float sy) {
         const float cx = clamp_coord(sx, t.wm1);
         const float cy = clamp_coord(sy, t.hm1);
-        ax = __builtin_amdgcn_fractf(cx);  // v_fract_f32: x - floor(x), kept below 1
-        ay = __builtin_amdgcn_fractf(cy);
+        ax = tex_fraction(__builtin_amdgcn_fractf(cx));  // v_fract_f32: x - floor(x), kept below 1
+        ay = tex_fraction(__builtin_amdgcn_fractf(cy));
         const int idx = texel_index(t, floor_to_int(cy), floor_to_int(cx));
 #ifdef PM_DBG_NOLOAD  // measurement builds only (results are wrong): the instruction stream without its gathers
         q = (f32x4q){(float)idx, 1.0f, ax, ay};
@@ -565,8 +576,8 @@ struct BilinearTap<true> {
     PM_DEV void issue(const TEX& t, float sx, float sy) {
         const float cx = clamp_coord(sx, t.wm1);
         const float cy = clamp_coord(sy, t.hm1);
-        ax = __builtin_amdgcn_fractf(cx);
-        ay = __builtin_amdgcn_fractf(cy);
+        ax = tex_fraction(__builtin_amdgcn_fractf(cx));
+        ay = tex_fraction(__builtin_amdgcn_fractf(cy));
         [[maybe_unused]] const int idx = texel_index(t, floor_to_int(cy), floor_to_int(cx));
 #ifdef PM_DBG_NOLOAD  // measurement builds only (results are wrong): the instruction stream without its gathers
         q = (u32x2q){(uint32_t)idx, (uint32_t)idx};

@@ -21,6 +21,7 @@ _EXTRA = {
     "wait": (C.c_int, [_P]),
     "verify_rcp": (C.c_int, [C.POINTER(C.c_ulonglong)]),
     "device_count": (C.c_int, []),
+    "texture_filter_bits": (C.c_int, []),
     "set_src_depths_device": (C.c_int, [_P, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "export_depth_device": (C.c_int, [_P, _P]),
     "set_profiling": (C.c_int, [_P, C.c_int]),
@@ -65,12 +66,35 @@ def load():
     return lib, fns
 
 
+LIB_Q8_PATH = os.path.join(_HERE, "csrc", "libmpmvs_hip_q8.so")
+
+
+def load_variant(path):
+    """a second build of the library next to the default one (the opt-in 8-bit-fraction twin, measurement builds): its own
+    dlopen handle and function table; contexts are made with create(device, fns=...)"""
+    if path in _cache:
+        return _cache[path]
+    load()   # torch's HIP runtime first (see load)
+    if not os.path.exists(path):
+        raise RuntimeError(f"HIP library not built: {path}")
+    lib = C.CDLL(path)
+    fns = _abi.bind(lib, "mpmvs_")
+    for name, (res, args) in _EXTRA.items():
+        fn = getattr(lib, "mpmvs_" + name)
+        fn.restype = res
+        fn.argtypes = args
+        fns[name] = fn
+    _cache[path] = (lib, fns)
+    return lib, fns
+
+
 class HipPatchMatch(_abi.PatchMatchHandle):
     """One PatchMatch context on one MI355X (the device-side half of the
     reference's PatchMatchCUDA object, reference include/PatchMatch.h:87-154)."""
 
-    def __init__(self, device=0):
-        _, fns = load()
+    def __init__(self, device=0, fns=None):
+        if fns is None:
+            _, fns = load()
         ctx = fns["create"](int(device))
         if not ctx:
             msg = fns["last_error"](None)
@@ -168,5 +192,10 @@ def device_count():
     return load()[1]["device_count"]()
 
 
-def create(device=0):
-    return HipPatchMatch(device)
+def create(device=0, fns=None):
+    return HipPatchMatch(device, fns)
+
+
+def create_q8(device=0):
+    """a context of the opt-in build with CUDA's 8-bit texture interpolation fractions (libmpmvs_hip_q8.so)"""
+    return HipPatchMatch(device, load_variant(LIB_Q8_PATH)[1])

@@ -65,6 +65,15 @@ def set_literal_mode(handle, mode):
         raise RuntimeError("orc_set_literal_mode failed")
 
 
+def set_texture_q8(handle, on=True):
+    """canonical arithmetic with CUDA's 8-bit texture interpolation fractions: the checker of the opt-in build libmpmvs_hip_q8.so"""
+    l, _ = lib()
+    l.orc_set_texture_q8.restype = C.c_int
+    l.orc_set_texture_q8.argtypes = [C.c_void_p, C.c_int]
+    if l.orc_set_texture_q8(handle._ctx, 1 if on else 0) != 0:
+        raise RuntimeError("orc_set_texture_q8 failed")
+
+
 def eval_ncc_literal(handle, params, planes_cam, scale, quantize_fraction=False, mode=None):
     """NCC in the reference's literal operation order (see pm_oracle.cpp); measurement only.  mode 1: IEEE + libm; 2: with CUDA's
     8-bit texture fractions (= quantize_fraction); 3: the fast-math model of the reference's build"""

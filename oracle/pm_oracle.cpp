@@ -282,6 +282,7 @@ struct Ctx {
     std::vector<uint32_t> mask;
     bool have_prior = false;
     int literal_mode = 0;  // 0 canonical; 1-3 measurement modes of the WHOLE path (see m_div / m_exp above)
+    bool tex_q8 = false;   // canonical arithmetic with 8-bit interpolation fractions: the checker of libmpmvs_hip_q8.so
     std::string err;
 };
 
@@ -494,14 +495,18 @@ inline void ref_window(const Ctx& c, const Params& prm, int px, int py, int scal
 
 // software bilinear, texel centres at integer coordinates, clamp addressing
 // (CUDA tex2D(t, x+0.5, y+0.5) with linear filtering; ref .cu:377, SURVEY a-2)
-inline float bilinear(const Image& im, float sx, float sy) {
+inline float bilinear(const Image& im, float sx, float sy, bool q8 = false) {
     const float wm1 = (float)(im.w - 1), hm1 = (float)(im.h - 1);
     float cx = (sx >= -1.0f) ? sx : -1.0f;
     cx = (cx <= wm1) ? cx : wm1;
     float cy = (sy >= -1.0f) ? sy : -1.0f;
     cy = (cy <= hm1) ? cy : hm1;
     const float fx = floorf(cx), fy = floorf(cy);
-    const float ax = det_fract(cx), ay = det_fract(cy);
+    float ax = det_fract(cx), ay = det_fract(cy);
+    if (q8) {  // CUDA's texture unit: 8 bits of fraction (pm_device.hpp tex_fraction; the product by 256 is exact, one rounding in the sum)
+        ax = floorf(ax * 256.0f + 0.5f) * 0.00390625f;
+        ay = floorf(ay * 256.0f + 0.5f) * 0.00390625f;
+    }
     const int ix = (int)fx, iy = (int)fy;
     const float t00 = im.at(ix, iy), t10 = im.at(ix + 1, iy);
     const float t01 = im.at(ix, iy + 1), t11 = im.at(ix + 1, iy + 1);
@@ -572,7 +577,7 @@ inline float ncc_cost(const Ctx& c, const RefWin& rw, int px, int py, const floa
             I[5] = iq2 * Z[4];
         }
         for (int b = 0; b < 6; ++b) {
-            const float sv = bilinear(src, X[b] * I[b], Y[b] * I[b]);
+            const float sv = bilinear(src, X[b] * I[b], Y[b] * I[b], c.tex_q8);
             const float w = rw.w[a * 6 + b];
             const float ws = w * sv;
             if ((b & 1) == 0) {
@@ -1494,6 +1499,13 @@ int orc_eval_geom_literal(orc_ctx* h, const void* params, const float* planes_ca
             const F4 pl = ((const F4*)planes_cam4)[(size_t)y * c.W + x];
             for (int v = 0; v < V; ++v) out[(size_t)v * wh + (size_t)y * c.W + x] = geom_cost_literal(c, v, pl, x, y);
         }
+    return 0;
+}
+
+// canonical arithmetic with CUDA's 8-bit interpolation fractions: what libmpmvs_hip_q8.so computes
+int orc_set_texture_q8(orc_ctx* h, int on) {
+    if (!h) return -1;
+    h->c.tex_q8 = on != 0;
     return 0;
 }
 

@@ -16,7 +16,8 @@ def pytest_configure(config):
 
 def _ensure_built():
     """native libraries are git-ignored build products: build them if a fresh checkout lacks them"""
-    libs = [os.path.join(ROOT, "mp-mvs_amd", "csrc", "libmpmvs_hip.so"), os.path.join(ROOT, "mp-mvs_amd", "host", "libmpmvs_host.so"),
+    libs = [os.path.join(ROOT, "mp-mvs_amd", "csrc", "libmpmvs_hip.so"), os.path.join(ROOT, "mp-mvs_amd", "csrc", "libmpmvs_hip_q8.so"),
+            os.path.join(ROOT, "mp-mvs_amd", "host", "libmpmvs_host.so"),
             os.path.join(ROOT, "oracle", "liboracle.so")]
     if not all(os.path.exists(p) for p in libs):
         import __graft_entry__ as g
