@@ -380,7 +380,14 @@ PM_DEV void load_ref_tile(const ProblemDev& P, float* tile, int x0, int y0, int 
 template <int SCALE, class TAP>
 PM_DEV void ref_window(float4* lw, TAP tap, const float (&spatial)[36], float two_sc, RefWin& rw) {
     constexpr int step = 2 << SCALE, radius = 5 * step / 2;
+    // all 37 reference values first, in straight-line code: read inside the weight loop below, every tap waited for its own LDS /
+    // memory round trip (14 separate waits at scale 2, where the window comes from global memory)
     const float rc = tap(0, 0);
+    float rv[36];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) rv[a * 6 + b] = tap(a * step - radius, b * step - radius);
     float sw = 0.0f, swr = 0.0f, swrr = 0.0f;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
@@ -388,8 +395,7 @@ PM_DEV void ref_window(float4* lw, TAP tap, const float (&spatial)[36], float tw
         float wv[6], wrv[6];
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
-            const int dx = a * step - radius, dy = b * step - radius;
-            const float r = tap(dx, dy);
+            const float r = rv[a * 6 + b];
             const float e = spatial[a * 6 + b] - __builtin_fabsf(r - rc) / two_sc;  // ref .cu:318-323
             const float w = d_exp_select(e);
             const float wr = w * r;
