@@ -1,5 +1,9 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_parity_gpu.py tests/test_golden_gpu.py tests/test_fuzz_gpu.py -x -q 2>&1 | tail -2
-python tools/bench_launches.py 2>/dev/null | tail -1
-bash tools/trace_kernels.sh cfg23 tools/bench_configs.py 2>&1 | head -9
+mkdir -p gpurun_out/r4p
+python bench.py --no-secondary --no-cpu-baseline > /dev/null 2>&1
+bash tools/profile_gpu.sh r04z > gpurun_out/r4p/profile.log 2>&1; echo "profile rc=$?"
+bash tools/trace_kernels.sh r04 bench.py --steps 5 --warmup 1 --no-secondary --no-cpu-baseline --no-overlap-phase > gpurun_out/r4p/trace.log 2>&1
+bash tools/trace_kernels.sh cfg23 tools/bench_configs.py > gpurun_out/r4p/cfg23.log 2>&1
+python bench.py > gpurun_out/r4p/bench.json 2> gpurun_out/r4p/bench.err; echo "bench rc=$?"
+python tools/kernel_resources.py > gpurun_out/r4p/kernel_resources.txt 2>&1
