@@ -549,3 +549,31 @@ def test_sealed_map_notices_a_direct_write(hostlib):
     assert lib.mpmvs_host_test_seal(a.ctypes.data, 1200, 1600, 0, a.size, 3.0) == 0            # a whole new map
     assert lib.mpmvs_host_test_seal(a.ctypes.data, 1200, 1600, 600 * 1600, 40 * 1600, 3.0) == 0  # a band of rows
     assert lib.mpmvs_host_test_seal(a.ctypes.data, 1200, 1600, a.size - 1, 1, 3.0) == 0        # the last element
+
+
+def test_bench_quotes_pmc_figures_only_for_this_build_and_this_run(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic / valu_busy_from_profile come from a committed rocprofv3 PMC summary -- but only while that summary
+    carries the hash of the HIP library in use and its kernel-trace average of k_update lies within 3 % of the run's own; otherwise
+    the fields are None and a reason is given (a stale profile must not be quoted silently)"""
+    import bench
+    lib = tmp_path / "libfake.so"
+    lib.write_bytes(b"binary one")
+    monkeypatch.setenv("MPMVS_HIP_LIB", str(lib))
+    h = bench.kernel_build_sha256()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r99z_pmc_summary_cfg1.txt").write_text(
+        f"# kernel_build_sha256: {h}\n# command: python3 bench.py\n# git_head: abc1234\n== kernel trace (ms) ==\n"
+        "k_update           calls  126  total   335.914  avg   2.6660  min   2.4573  max   3.6558   91.2%\n"
+        "== pmc_fetch (per-dispatch average) ==\n  k_update  vgpr/agpr/sgpr/scratch/lds = ('116', '0', '112', '352', '0')\n      FETCH_SIZE   n=126 avg=400000\n"
+        "== pmc_write (per-dispatch average) ==\n  k_update  vgpr = x\n      WRITE_SIZE   n=126 avg=300000\n"
+        "== pmc_sq1 ==\n  k_update  vgpr = x\n      SQ_ACTIVE_INST_VALU  n=126 avg=1.0e+09\n== pmc_grbm ==\n  k_update  vgpr = x\n      GRBM_GUI_ACTIVE  n=126 avg=5.0e+07\n")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    ok = bench.profile_counters(2.70)
+    assert ok["reason"] is None and ok["traffic"] == 700000 * 1024.0 and ok["traffic_if_fetch_doubled"] == 1100000 * 1024.0
+    assert abs(ok["valu_busy"] - 1.0e9 * 4 / (1024 * 5.0e7 / 8)) < 1e-4 and "abc1234" in ok["source"]
+    far = bench.profile_counters(3.00)                       # this run's launches are 12 % slower than the profiled ones
+    assert far["traffic"] is None and far["valu_busy"] is None and "3 %" in far["reason"]
+    lib.write_bytes(b"binary two")                           # another build of the kernels
+    stale = bench.profile_counters(2.70)
+    assert stale["traffic"] is None and "another kernel build" in stale["reason"]
