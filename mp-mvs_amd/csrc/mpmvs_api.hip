@@ -574,6 +574,75 @@ void mpmvs_destroy(mpmvs_ctx* c) {
 
 const char* mpmvs_last_error(const mpmvs_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
+// Exactness of the images without staging anything (the first pass of an upload in bounded slices): is the reference image / is
+// every source image made of integers in [0, 255]?  Row chunks on the pool; a group's rows are skipped once its flag has dropped.
+static void probe_exact(int n, const mpmvs_camera* cams, const float* const* images, const size_t* pitch_bytes, bool try_src_u8, bool& ref_u8, bool& src_u8) {
+    std::vector<long> row0(n + 1, 0);
+    for (int i = 0; i < n; ++i) row0[i + 1] = row0[i] + cams[i].height;
+    const long total_rows = row0[n];
+    std::atomic<bool> ref_exact(true), src_exact(try_src_u8);
+    std::atomic<long> next(0);
+    const std::function<void()> work = [&]() {
+        const long chunk = 32;
+        for (;;) {
+            const long r0 = next.fetch_add(chunk);
+            if (r0 >= total_rows) return;
+            int i = 0;
+            while (r0 >= row0[i + 1]) ++i;
+            for (long k = r0; k < std::min(r0 + chunk, total_rows); ++k) {
+                while (k >= row0[i + 1]) ++i;
+                std::atomic<bool>& exact = i == 0 ? ref_exact : src_exact;
+                if (!exact.load(std::memory_order_relaxed)) continue;
+                const int y = (int)(k - row0[i]), w = cams[i].width;
+                const size_t pitch = pitch_bytes ? pitch_bytes[i] : (size_t)w * 4;
+                const float* row = (const float*)((const char*)images[i] + (size_t)y * pitch);
+                bool ok = true;
+                for (int x = 0; x < w; ++x) {
+                    const float f = row[x];
+                    const int q = (int)(f >= 0.0f && f <= 255.0f ? f : -1.0f);
+                    ok &= (float)q == f;
+                }
+                if (!ok) exact.store(false, std::memory_order_relaxed);
+            }
+        }
+    };
+    row_pool().run(work);
+    ref_u8 = ref_exact.load();
+    src_u8 = src_exact.load();
+}
+
+// Stages images [first, last) whose formats are already known (ref_u8 / src_u8): bytes or fp32 rows into `stage` at slot[i] - slot[first]
+static void stage_known(int first, int last, const mpmvs_camera* cams, const float* const* images, const size_t* pitch_bytes, char* stage,
+                        const std::vector<size_t>& slot, bool ref_u8, bool src_u8) {
+    std::vector<long> row0(last - first + 1, 0);
+    for (int i = first; i < last; ++i) row0[i - first + 1] = row0[i - first] + cams[i].height;
+    const long total_rows = row0[last - first];
+    std::atomic<long> next(0);
+    const std::function<void()> work = [&]() {
+        const long chunk = 32;
+        for (;;) {
+            const long r0 = next.fetch_add(chunk);
+            if (r0 >= total_rows) return;
+            int g = 0;
+            while (r0 >= row0[g + 1]) ++g;
+            for (long k = r0; k < std::min(r0 + chunk, total_rows); ++k) {
+                while (k >= row0[g + 1]) ++g;
+                const int i = first + g, y = (int)(k - row0[g]), w = cams[i].width;
+                const size_t pitch = pitch_bytes ? pitch_bytes[i] : (size_t)w * 4;
+                const float* row = (const float*)((const char*)images[i] + (size_t)y * pitch);
+                char* base = stage + (slot[i] - slot[first]);
+                if (i == 0 ? ref_u8 : src_u8) {
+                    unsigned char* o = (unsigned char*)base + (size_t)y * w;
+                    for (int x = 0; x < w; ++x) o[x] = (unsigned char)(int)row[x];
+                } else {
+                    std::memcpy(base + (size_t)y * w * 4, row, (size_t)w * 4);
+                }
+            }
+        }
+    };
+    row_pool().run(work);
+}
+
 static int set_views_impl(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const float* const* images, const size_t* pitch_bytes) {
     c->n_img = n;
     c->cams.assign(cams, cams + n);
@@ -584,41 +653,45 @@ static int set_views_impl(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const f
     // host staging (page-locked, pooled) and its device twin: a slot of w * h floats per image, 256-byte aligned
     std::vector<size_t> slot(n + 1, 0);
     for (int i = 0; i < n; ++i) slot[i + 1] = slot[i] + (((size_t)cams[i].width * cams[i].height * 4 + 255) & ~(size_t)255);
+    // The images are staged in GROUPS of consecutive views of at most MPMVS_STAGE_MB (default 512) megabytes: ordinary inputs are
+    // one group (one pass over the images that decides the formats while it stages, one synchronisation per call); very many large
+    // views (33 x 3200 x 3200 floats = 1.35 GB) go through bounded staging buffers that are re-used group by group, after a first
+    // pass that only decides the formats (the texture format of the sources must be known before the first of them is packed).
+    size_t limit = 512;
+    if (const char* e = std::getenv("MPMVS_STAGE_MB")) limit = (size_t)std::max(1, std::atoi(e));
+    limit <<= 20;
+    std::vector<int> group_first{0};
+    for (int i = 1; i < n; ++i)
+        if (slot[i + 1] - slot[group_first.back()] > limit) group_first.push_back(i);
+    group_first.push_back(n);
+    const int n_groups = (int)group_first.size() - 1;
+    size_t stage_bytes = 0;
+    for (int g = 0; g < n_groups; ++g) stage_bytes = std::max(stage_bytes, slot[group_first[g + 1]] - slot[group_first[g]]);
     PinnedBuf stage;
-    stage.p = mpmvs_alloc_pinned(slot[n]);
+    stage.p = mpmvs_alloc_pinned(stage_bytes);
     if (!stage.p) return fail(c, -100, "no page-locked staging memory for the images");
     bool ref_u8 = false, src_u8 = false;
     // 8-bit exact sources (the reference's imread path, ref .cpp:877-882) take the 8-byte fp16 texel format; anything else,
     // or force_f32, the 16-byte fp32 one
-    stage_images(n, cams, images, pitch_bytes, !c->force_f32, (char*)stage.p, slot, ref_u8, src_u8);
+    if (n_groups == 1)
+        stage_images(n, cams, images, pitch_bytes, !c->force_f32, (char*)stage.p, slot, ref_u8, src_u8);
+    else
+        probe_exact(n, cams, images, pitch_bytes, !c->force_f32, ref_u8, src_u8);
     c->all_u8 = src_u8;
     PoolBuf d_stage;  // back to the pool when the call returns; every return path synchronises the stream first
-    HIPCHK(c, d_stage.alloc(slot[n]));
-    int rc = 0;
+    HIPCHK(c, d_stage.alloc(stage_bytes));
     auto failed = [&](const char* what) {
         (void)hipStreamSynchronize(c->stream);
         c->err = what;
         return -100;
     };
-    for (int i = 0; i < n && !rc; ++i) {
-        const size_t bytes = (size_t)cams[i].width * cams[i].height * ((i == 0 ? ref_u8 : src_u8) ? 1 : 4);
-        if (hipMemcpyAsync(d_stage.as<char>() + slot[i], (const char*)stage.p + slot[i], bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = -100;
-    }
-    if (rc) return failed("upload of the images failed");
-    // reference image: replicate-padded fp32
-    {
-        const int pw = c->W + 2 * kRefApron, ph = c->H + 2 * kRefApron;
-        if (pool_malloc(&c->d_ref, (size_t)pw * ph * 4) != hipSuccess) return failed("allocation of the reference image failed");
-        if (ref_u8)
-            hipLaunchKernelGGL(k_pad_u8, dim3((pw + 255) / 256, ph), dim3(256), 0, c->stream, d_stage.as<unsigned char>() + slot[0], c->W, c->H, c->d_ref, kRefApron);
-        else
-            hipLaunchKernelGGL(k_pad, dim3((pw + 255) / 256, ph), dim3(256), 0, c->stream, (const float*)(d_stage.as<char>() + slot[0]), c->W, c->H, c->d_ref, kRefApron);
-        c->hP.ref_pitch = pw;
-        c->hP.ref_img = c->d_ref + (size_t)kRefApron * pw + kRefApron;
-    }
-    // one allocation for the textures of all views, each 256-byte aligned.  Every view is addressed through its own buffer
-    // resource (base = the view's first texel, 32-bit offsets inside it), so only a single view is limited to 4 GB
-    // (checked by the caller), not the allocation: 32 views of 3200 x 3200 fp32 texels are 5.2 GB.
+    // reference image (replicate-padded fp32) and one allocation for the textures of all views, each 256-byte aligned.  Every
+    // view is addressed through its own buffer resource (base = the view's first texel, 32-bit offsets inside it), so only a
+    // single view is limited to 4 GB (checked by the caller), not the allocation: 32 views of 3200 x 3200 fp32 texels are 5.2 GB.
+    const int pw = c->W + 2 * kRefApron, ph = c->H + 2 * kRefApron;
+    if (pool_malloc(&c->d_ref, (size_t)pw * ph * 4) != hipSuccess) return failed("allocation of the reference image failed");
+    c->hP.ref_pitch = pw;
+    c->hP.ref_img = c->d_ref + (size_t)kRefApron * pw + kRefApron;
     const size_t texel = src_u8 ? 8 : 16;
     std::vector<size_t> tex_off(n, 0);
     size_t tex_total = 0;
@@ -628,21 +701,43 @@ static int set_views_impl(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const f
     }
     if (pool_malloc(&c->d_tex_all, tex_total) != hipSuccess) return failed("allocation of the source textures failed");
     if (src_u8) c->d_src8.assign(n - 1, nullptr); else c->d_src.assign(n - 1, nullptr);
-    for (int v = 1; v < n; ++v) {
-        const int w = cams[v].width, h = cams[v].height;
-        ViewDev& o = c->hP.views[v - 1];
-        if (src_u8) {
-            c->d_src8[v - 1] = (uint32_t*)((char*)c->d_tex_all + tex_off[v]);
-            hipLaunchKernelGGL(k_pack_quads_u8, dim3((w + 255) / 256, h), dim3(256), 0, c->stream, d_stage.as<unsigned char>() + slot[v], w, h, (uint2*)c->d_src8[v - 1]);
-            o.pitch8 = w;
-            o.img8 = c->d_src8[v - 1];
-        } else {
-            c->d_src[v - 1] = (float*)((char*)c->d_tex_all + tex_off[v]);
-            hipLaunchKernelGGL(k_pack_quads_f32, dim3((w + 255) / 256, h), dim3(256), 0, c->stream, (const float*)(d_stage.as<char>() + slot[v]), w, h, (float4*)c->d_src[v - 1]);
-            o.pitch = w;
-            o.img = c->d_src[v - 1];
+    for (int g = 0; g < n_groups; ++g) {
+        const int first = group_first[g], last = group_first[g + 1];
+        if (n_groups > 1) {
+            if (g > 0 && hipStreamSynchronize(c->stream) != hipSuccess) return failed("upload of the images failed");  // the staging buffers are free again
+            stage_known(first, last, cams, images, pitch_bytes, (char*)stage.p, slot, ref_u8, src_u8);
+        }
+        for (int i = first; i < last; ++i) {
+            const size_t off = slot[i] - slot[first];
+            const size_t bytes = (size_t)cams[i].width * cams[i].height * ((i == 0 ? ref_u8 : src_u8) ? 1 : 4);
+            if (hipMemcpyAsync(d_stage.as<char>() + off, (const char*)stage.p + off, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+                return failed("upload of the images failed");
+        }
+        for (int v = first; v < last; ++v) {
+            const char* src = d_stage.as<char>() + (slot[v] - slot[first]);
+            const int w = cams[v].width, h = cams[v].height;
+            if (v == 0) {
+                if (ref_u8)
+                    hipLaunchKernelGGL(k_pad_u8, dim3((pw + 255) / 256, ph), dim3(256), 0, c->stream, (const unsigned char*)src, c->W, c->H, c->d_ref, kRefApron);
+                else
+                    hipLaunchKernelGGL(k_pad, dim3((pw + 255) / 256, ph), dim3(256), 0, c->stream, (const float*)src, c->W, c->H, c->d_ref, kRefApron);
+                continue;
+            }
+            ViewDev& o = c->hP.views[v - 1];
+            if (src_u8) {
+                c->d_src8[v - 1] = (uint32_t*)((char*)c->d_tex_all + tex_off[v]);
+                hipLaunchKernelGGL(k_pack_quads_u8, dim3((w + 255) / 256, h), dim3(256), 0, c->stream, (const unsigned char*)src, w, h, (uint2*)c->d_src8[v - 1]);
+                o.pitch8 = w;
+                o.img8 = c->d_src8[v - 1];
+            } else {
+                c->d_src[v - 1] = (float*)((char*)c->d_tex_all + tex_off[v]);
+                hipLaunchKernelGGL(k_pack_quads_f32, dim3((w + 255) / 256, h), dim3(256), 0, c->stream, (const float*)src, w, h, (float4*)c->d_src[v - 1]);
+                o.pitch = w;
+                o.img = c->d_src[v - 1];
+            }
         }
     }
+    int rc = 0;
     if (hipGetLastError() != hipSuccess) return failed("unpacking the images on the device failed");
     const size_t wh = (size_t)c->W * c->H;
     rc = -100;

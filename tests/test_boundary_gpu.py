@@ -247,3 +247,36 @@ def test_pinned_host_buffers_round_trip(pm, engine):
     assert again == p_planes                                        # handed out again from the pool
     fns["free_pinned"](again)
     fns["free_pinned"](p_costs)
+
+
+@pytest.mark.parametrize("quantize", [True, False])
+def test_set_views_in_bounded_staging_groups(pm, engine, monkeypatch, quantize):
+    """very many large views are staged in groups of at most MPMVS_STAGE_MB megabytes through re-used buffers (a first pass decides
+    the texture formats, then every group is converted, uploaded and packed): the same textures -- the same results -- as the
+    one-shot upload, for 8-bit exact and for non-integer images, and also when only ONE source image is not 8-bit exact"""
+    W, H, V = 400, 300, 8
+    sc = pm.synth.make_problem_scene(W, H, n_src=V, quantize=quantize)
+    cams, imgs = sc.problem(0, list(range(1, V + 1)))
+    dmin, dmax = pm.synth.kernel_depth_range(cams[0])
+    prm = pm.PatchMatchParams(num_images=V + 1, depth_min=float(dmin), depth_max=float(dmax), max_scale=1)
+
+    def result(images, stage_mb):
+        if stage_mb:
+            monkeypatch.setenv("MPMVS_STAGE_MB", str(stage_mb))
+        else:
+            monkeypatch.delenv("MPMVS_STAGE_MB", raising=False)
+        h = engine.create(0)
+        h.set_views(cams, images)
+        h.run(prm, 77)
+        return h.texture_format(), h.get()
+
+    fmt0, (p0, c0) = result(imgs, None)
+    fmt1, (p1, c1) = result(imgs, 1)        # 1 MB: two 400x300 fp32 slots per group -> five groups
+    assert fmt0 == fmt1 == ("u8" if quantize else "f32")
+    assert np.array_equal(p0, p1) and np.array_equal(c0, c1)
+    if quantize:
+        mixed = [im.copy() for im in imgs]
+        mixed[6][100, 200] += 0.25          # one inexact pixel in one source: every source takes the fp32 format
+        fmt2, (p2, c2) = result(mixed, None)
+        fmt3, (p3, c3) = result(mixed, 1)
+        assert fmt2 == fmt3 == "f32" and np.array_equal(p2, p3) and np.array_equal(c2, c3)
