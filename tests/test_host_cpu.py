@@ -36,6 +36,11 @@ def test_c_abi_exports_every_declared_symbol(pm):
         assert hasattr(lib, name), f"{name} declared in include/mpmvs.h but not exported"
     for name in engine.ALL_SYMBOLS:
         assert name in declared, f"{name} bound in Python but not declared in include/mpmvs.h"
+    # the opt-in twin with 8-bit texture fractions is the same ABI
+    lib_q8, _ = engine.load_variant(engine.LIB_Q8_PATH)
+    for name in declared:
+        assert hasattr(lib_q8, name), f"{name} declared in include/mpmvs.h but not exported by libmpmvs_hip_q8.so"
+    assert lib.mpmvs_texture_filter_bits() == 0 and lib_q8.mpmvs_texture_filter_bits() == 8   # a host function: no GPU needed
 
 
 def test_abi_struct_layouts(pm):

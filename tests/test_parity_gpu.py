@@ -215,6 +215,27 @@ def test_geom_cost_bit_exact(pm, oracle, engine):
     assert got.max() <= 3.0 and (got < 3.0).mean() > 0.05
 
 
+def test_view_selection_threshold_beyond_three_iterations_bit_exact(pm, oracle, engine):
+    """`cost_threshold = 0.8 * expf(iter * iter / -90)` (ref .cu:832) multiplies in DOUBLE and rounds once; the kernel gets it from the
+    host per launch (LaunchArgs::cost_threshold), the oracle forms it itself.  For the iterations Run() uses by default (0..2) the
+    double and the float product round to the same bits; from iteration 3 on they differ -- a Run() with 12 iterations walks through
+    those, and single steps at iterations 84 / 85 / 200 cross the point where the exponential's argument leaves the range of the
+    canonical exp (threshold exactly 0)"""
+    sc, gpu, cpu, prm = make_pair(pm, oracle, engine, 56, 40, 3, quantize=True)
+    prm.max_iterations = 12
+    for h in (gpu, cpu):
+        h.run(prm, SEED)
+    compare_state(gpu, cpu, "12 iterations")
+    p0, c0 = cpu.get()
+    for it in (3, 84, 85, 200):
+        for h in (gpu, cpu):
+            h.set_state(p0, c0)
+            h.step(prm, SEED + it, pm.KIND_INIT, 0, 0, 0)      # photometric: fresh random planes
+            h.step(prm, SEED + it, pm.KIND_BLACK, it, 0, 1)
+            h.step(prm, SEED + it, pm.KIND_RED, it, 0, 2)
+        compare_state(gpu, cpu, f"iteration {it}")
+
+
 def test_geom_cost_full_intrinsics_and_sizes_bit_exact(pm, oracle, engine):
     """the composed maps of the geometric check are formed on the host of BOTH implementations from the cameras:
     per-view intrinsics with skew and off-diagonal terms (ProjectPoint uses all of K, BackProjectPoint2W only fx, fy, cx, cy),
