@@ -80,6 +80,9 @@ struct mpmvs_ctx {
 };
 
 static thread_local std::string g_create_err;
+#ifdef PM_DBG_WAVETIME
+static size_t kWaveTimeBytes(int W, int H) { return (size_t)16 * ((size_t)(W / 16 + 2) * (H / 8 + 8)) * 4 * 8; }
+#endif
 
 #define HIPCHK(ctx, expr)                                                                           \
     do {                                                                                            \
@@ -246,6 +249,9 @@ static void free_views(mpmvs_ctx* c) {
     if (c->S.sel) (void)pool_free(c->S.sel);
     if (c->S.geom) (void)pool_free(c->S.geom);
     if (c->S.depth) (void)pool_free(c->S.depth);
+#ifdef PM_DBG_WAVETIME
+    if (c->S.wavetime) (void)hipFree(c->S.wavetime);
+#endif
     if (c->stage_planes) (void)pool_free(c->stage_planes);
     if (c->stage_costs) (void)pool_free(c->stage_costs);
     if (c->stage_geom) (void)pool_free(c->stage_geom);
@@ -747,6 +753,10 @@ static int set_views_impl(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const f
         hipMemsetAsync(c->S.sel, 0, wh * 4, c->stream) == hipSuccess && hipMemsetAsync(c->S.geom, 0, wh * 4, c->stream) == hipSuccess)
         rc = 0;
     c->depth_plane_valid = false;
+#ifdef PM_DBG_WAVETIME
+    // room for 16 launches of one wave per 64 pixels of a colour, 4 x u64 each (generous: blocks overhang the image border)
+    if (!rc && (hipMalloc(&c->S.wavetime, kWaveTimeBytes(c->W, c->H)) != hipSuccess || hipMemsetAsync(c->S.wavetime, 0, kWaveTimeBytes(c->W, c->H), c->stream) != hipSuccess)) rc = -100;
+#endif
     if (rc) c->err = "allocation of the per-pixel state failed";
     const int rc_up = upload_problem(c);  // synchronises the stream (also on the failure path): both staging buffers are free again
     return rc ? rc : rc_up;
@@ -913,6 +923,18 @@ int mpmvs_set_prior(mpmvs_ctx* c, const void* prior4, const void* mask) {
 // ---------------------------------------------------------------------------
 // launches
 // ---------------------------------------------------------------------------
+#ifdef PM_DBG_WAVETIME
+// measurement builds: the per-wave records of the last <= 16 update launches ([launch % 16][wave][4] u64; pm_kernels.hpp, WaveTimer)
+extern "C" long mpmvs_dbg_wavetime(mpmvs_ctx* c, void* out, size_t cap_bytes) {
+    if (!c || !c->S.wavetime) return -1;
+    if (enter_device(c->device) != hipSuccess) return -1;
+    const size_t n = kWaveTimeBytes(c->W, c->H);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    if (out && hipMemcpy(out, c->S.wavetime, n < cap_bytes ? n : cap_bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (long)n;
+}
+#endif
+
 static int check_ready(mpmvs_ctx* c, const mpmvs_params* p) {
     if (c->n_img < 2) return fail(c, -1, "set_views not called (need >= 2 views)");
     if (p->num_images != c->n_img) return fail(c, -2, "params.num_images != number of views");
@@ -936,27 +958,28 @@ static hipEvent_t get_event(mpmvs_ctx* c) {
     return e;
 }
 
-template <bool U8>
+template <bool U8, int NT = 256>
 static dim3 checker_grid(const mpmvs_ctx* c, const LaunchArgs& a) {
     const int rows = c->H < a.ylimit ? c->H : a.ylimit;
-    return dim3(((c->W + kChkBlockW<U8> - 1) / kChkBlockW<U8>) * ((rows + kChkBlockH<U8> - 1) / kChkBlockH<U8>));
+    return dim3(((c->W + kChkBlockW<U8, NT> - 1) / kChkBlockW<U8, NT>) * ((rows + kChkBlockH<U8, NT> - 1) / kChkBlockH<U8, NT>));
 }
 // The per-view arrays of the update kernel (8 x V candidate costs and four V-vectors, in scratch) are sized by a template
 // bound on the number of source views: buckets of 8 keep that scratch and the register pressure around it proportional to the
 // Problem (the shipped configuration allows 20 views, reference config/config.yaml:19; the hard limit is 32, ref .cu:500).
 template <bool GEOM, bool PRIOR, bool U8, int SCALE>
 static void launch_update3(mpmvs_ctx* c, const LaunchArgs& a) {
-    const dim3 grid = checker_grid<U8>(c, a);
+    const dim3 grid = checker_grid<U8, kUpdThreads>(c, a);
     const size_t lds = update_lds_bytes();
+    const dim3 blk(kUpdThreads);
     const int V = c->hP.V;
     if (V <= 8)
-        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 8, U8, SCALE>), grid, dim3(256), lds, c->stream, c->dP, c->S, a);
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 8, U8, SCALE>), grid, blk, lds, c->stream, c->dP, c->S, a);
     else if (V <= 16)
-        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 16, U8, SCALE>), grid, dim3(256), lds, c->stream, c->dP, c->S, a);
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 16, U8, SCALE>), grid, blk, lds, c->stream, c->dP, c->S, a);
     else if (V <= 24)
-        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 24, U8, SCALE>), grid, dim3(256), lds, c->stream, c->dP, c->S, a);
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 24, U8, SCALE>), grid, blk, lds, c->stream, c->dP, c->S, a);
     else
-        hipLaunchKernelGGL((k_update<GEOM, PRIOR, kMaxViews, U8, SCALE>), grid, dim3(256), lds, c->stream, c->dP, c->S, a);
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, kMaxViews, U8, SCALE>), grid, blk, lds, c->stream, c->dP, c->S, a);
 }
 // The window scale is a template parameter of the NCC kernels (pm_device.hpp, Win).  The photometric update exists at the
 // scales 0..2 of the multi-scale schedule; the geometric and the prior update run at scale 0 only, as Run() does (ref
@@ -1139,9 +1162,12 @@ static int abandon_run(mpmvs_ctx* c, int rc) {
     return rc;
 }
 
-static int enqueue_run(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, void* planes4, void* costs, void* geom) {
+// The launch schedule of Run() (ref .cu:1200-1244) in two halves, ONE copy of it for the blocking and the pipelined Run(): the
+// random streams are keyed by the launch numbers, so the two entry points give the same bits only while they number alike.
+// enqueue_updates: InitializeScore and every Black / RedPixelUpdate (costs and geometric costs are final afterwards);
+// enqueue_finalize: GetDepthandNormal and the two median-filter launches.
+static int enqueue_updates(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, uint32_t& launch) {
     int rc;
-    uint32_t launch = 0;
     if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_INIT, 0, p->max_scale, launch++))) return rc;
     if (p->geom_consistency || p->planar_prior) {
         for (int i = 0; i < p->max_iterations; ++i) {
@@ -1155,6 +1181,20 @@ static int enqueue_run(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, void*
                 if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_RED, i, s, launch++))) return rc;
             }
     }
+    return 0;
+}
+static int enqueue_finalize(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, uint32_t& launch) {
+    int rc;
+    if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_DEPTH_NORMAL, 0, 0, launch++))) return rc;
+    if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_FILTER_BLACK, 0, 0, launch++))) return rc;
+    if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_FILTER_RED, 0, 0, launch++))) return rc;
+    return 0;
+}
+
+static int enqueue_run(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, void* planes4, void* costs, void* geom) {
+    int rc;
+    uint32_t launch = 0;
+    if ((rc = enqueue_updates(c, p, seed, launch))) return rc;
     const size_t wh = (size_t)c->W * c->H;
     const bool early = costs || geom;
     if (early) {
@@ -1165,9 +1205,7 @@ static int enqueue_run(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, void*
         if (costs) HIPCHK(c, hipMemcpyAsync(costs, c->S.costs, wh * 4, hipMemcpyDeviceToHost, c->copy_stream));
         if (geom) HIPCHK(c, hipMemcpyAsync(geom, c->S.geom, wh * 4, hipMemcpyDeviceToHost, c->copy_stream));
     }
-    if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_DEPTH_NORMAL, 0, 0, launch++))) return rc;
-    if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_FILTER_BLACK, 0, 0, launch++))) return rc;
-    if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_FILTER_RED, 0, 0, launch++))) return rc;
+    if ((rc = enqueue_finalize(c, p, seed, launch))) return rc;
     if (planes4) HIPCHK(c, hipMemcpyAsync(planes4, c->S.planes, wh * 16, hipMemcpyDeviceToHost, c->stream));
     if (early) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     return finish(c);
@@ -1211,10 +1249,17 @@ int mpmvs_run_get_async(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, void
     int rc = check_ready(c, p);
     if (rc) return rc;
     const size_t wh = (size_t)c->W * c->H;
-    if (!c->stage_planes) {
-        if (pool_malloc(&c->stage_planes, wh * 16) != hipSuccess || pool_malloc(&c->stage_costs, wh * 4) != hipSuccess ||
-            pool_malloc(&c->stage_geom, wh * 4) != hipSuccess)
+    if (!c->stage_planes || !c->stage_costs || !c->stage_geom) {
+        // all three or none: a partial set left behind by a failed allocation would make the next call copy through a null pointer
+        if ((!c->stage_planes && pool_malloc(&c->stage_planes, wh * 16) != hipSuccess) || (!c->stage_costs && pool_malloc(&c->stage_costs, wh * 4) != hipSuccess) ||
+            (!c->stage_geom && pool_malloc(&c->stage_geom, wh * 4) != hipSuccess)) {
+            if (c->stage_planes) (void)pool_free(c->stage_planes);
+            if (c->stage_costs) (void)pool_free(c->stage_costs);
+            if (c->stage_geom) (void)pool_free(c->stage_geom);
+            c->stage_planes = nullptr;
+            c->stage_costs = c->stage_geom = nullptr;
             return fail(c, -100, "allocation of the staging buffers failed");
+        }
     }
     if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     if (!c->staged) HIPCHK(c, hipEventCreateWithFlags(&c->staged, hipEventDisableTiming));
@@ -1228,22 +1273,7 @@ int mpmvs_run_get_async(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, void
     uint32_t launch = 0;
     auto body = [&]() -> int {
         int r;
-        if ((r = enqueue_step(c, p, seed, MPMVS_KIND_INIT, 0, p->max_scale, launch++))) return r;
-        if (p->geom_consistency || p->planar_prior) {
-            for (int i = 0; i < p->max_iterations; ++i) {
-                if ((r = enqueue_step(c, p, seed, MPMVS_KIND_BLACK, i, 0, launch++))) return r;
-                if ((r = enqueue_step(c, p, seed, MPMVS_KIND_RED, i, 0, launch++))) return r;
-            }
-        } else {
-            for (int s = p->max_scale; s >= 0; --s)
-                for (int i = 0; i < p->max_iterations; ++i) {
-                    if ((r = enqueue_step(c, p, seed, MPMVS_KIND_BLACK, i, s, launch++))) return r;
-                    if ((r = enqueue_step(c, p, seed, MPMVS_KIND_RED, i, s, launch++))) return r;
-                }
-        }
-        if ((r = enqueue_step(c, p, seed, MPMVS_KIND_DEPTH_NORMAL, 0, 0, launch++))) return r;
-        if ((r = enqueue_step(c, p, seed, MPMVS_KIND_FILTER_BLACK, 0, 0, launch++))) return r;
-        if ((r = enqueue_step(c, p, seed, MPMVS_KIND_FILTER_RED, 0, 0, launch++))) return r;
+        if ((r = enqueue_updates(c, p, seed, launch)) || (r = enqueue_finalize(c, p, seed, launch))) return r;
         // the staging buffers are free once the previous call's copies have left them (a 0.7 ms copy against a whole Run())
         if (c->async_outstanding > 1) HIPCHK(c, hipStreamWaitEvent(c->stream, c->staging_free, 0));
         if (planes4) HIPCHK(c, hipMemcpyAsync(c->stage_planes, c->S.planes, wh * 16, hipMemcpyDeviceToDevice, c->stream));

@@ -68,6 +68,9 @@ struct StateDev {
     const float4* prior;
     const uint32_t* mask;
     float* depth;  // dense copy of planes[].w after GetDepthandNormal: what the median filter gathers (4 instead of 16 bytes per tap)
+#ifdef PM_DBG_WAVETIME
+    unsigned long long* wavetime;  // measurement builds: per-wave start / end stamps of the update launches (pm_kernels.hpp, WaveTimer)
+#endif
 };
 
 // ---------------------------------------------------------------------------
@@ -337,9 +340,11 @@ PM_DEV float4 perturbed_normal(const ProblemDev& P, int px, int py, const float4
 // for the whole update kernel (squeezed into 168 registers: slower) and for its phase A as a kernel of its own (fits easily:
 // exactly as fast as with two waves per SIMD): the third wave buys this workload nothing.
 // ---------------------------------------------------------------------------
-constexpr int kBlockThreads = 256;
+constexpr int kBlockThreads = 256;  // threads per block of the all-pixel NCC kernels (k_init, k_eval_ncc); the update kernel has its own (kUpdThreads)
 extern __shared__ float pm_lds[];  // dynamic LDS of the NCC kernels
-constexpr int kLdsWeightFloats = 2 * 36 * kBlockThreads;
+template <int NT>
+constexpr int kLdsWeightFloatsOf = 2 * 36 * NT;  // 18 float4 weight records per thread of an NT-thread block
+constexpr int kLdsWeightFloats = kLdsWeightFloatsOf<kBlockThreads>;
 
 struct RefWin {
     // this thread's LDS column, one float4 per pair of vertically adjacent taps
@@ -354,19 +359,20 @@ struct RefWin {
 // the sake of its prologue (measured 5.96 vs 3.9 ms per launch at scale 2), so the window is then read from the L2-resident
 // padded image instead.  With the 8 x 64 pixel blocks of the fp16 texture format that is the case from scale 1 on (28 x 84
 // floats), with the 16 x 32 blocks of the fp32 format and the 16 x 16 dense blocks from scale 2 on.
-template <int SCALE, int BW, int BH>
+template <int SCALE, int BW, int BH, int TILE_MAX = 2048>
 struct Win {
     static constexpr int step = 2 << SCALE, radius = 5 * step / 2, pitch = BW + 2 * radius, rows = BH + 2 * radius;
-    static constexpr bool tile_in_lds = pitch * rows <= 2048;
+    static constexpr bool tile_in_lds = pitch * rows <= TILE_MAX;
 };
 
 // cooperative load of the tile [x0-radius, x0+BW+radius) x [y0-radius, y0+BH+radius)
 // of the apron-padded reference image; columns/rows beyond the apron (only ever
 // addressed by threads whose pixel lies outside the image) are clamped
+template <int NT>
 PM_DEV void load_ref_tile(const ProblemDev& P, float* tile, int x0, int y0, int bw, int bh, int radius) {
     const int tw = bw + 2 * radius, th = bh + 2 * radius;
     const int xmin = -kRefApron, xmax = P.W + kRefApron - 1, ymin = -kRefApron, ymax = P.H + kRefApron - 1;
-    for (int i = threadIdx.x; i < tw * th; i += kBlockThreads) {
+    for (int i = threadIdx.x; i < tw * th; i += NT) {
         const int ty = i / tw, tx = i - ty * tw;
         int gx = x0 - radius + tx, gy = y0 - radius + ty;
         gx = gx < xmin ? xmin : (gx > xmax ? xmax : gx);
@@ -377,7 +383,7 @@ PM_DEV void load_ref_tile(const ProblemDev& P, float* tile, int x0, int y0, int 
 
 // weights of one pixel -> LDS column `lw`.  tap(dx, dy) reads the reference image at the pixel + (dx, dy): from the block's
 // LDS tile, or from the apron-padded image in global memory (see Win).
-template <int SCALE, class TAP>
+template <int SCALE, int NT, class TAP>
 PM_DEV void ref_window(float4* lw, TAP tap, const float (&spatial)[36], float two_sc, RefWin& rw) {
     constexpr int step = 2 << SCALE, radius = 5 * step / 2;
     // all 37 reference values first, in straight-line code: read inside the weight loop below, every tap waited for its own LDS /
@@ -406,7 +412,7 @@ PM_DEV void ref_window(float4* lw, TAP tap, const float (&spatial)[36], float tw
             pwrr = __builtin_fmaf(wr, r, pwrr);
         }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) lw[(a * 3 + j) * kBlockThreads] = make_float4(wv[2 * j], wv[2 * j + 1], wrv[2 * j], wrv[2 * j + 1]);
+        for (int j = 0; j < 3; ++j) lw[(a * 3 + j) * NT] = make_float4(wv[2 * j], wv[2 * j + 1], wrv[2 * j], wrv[2 * j + 1]);
         sw += pw;
         swr += pwr;
         swrr += pwrr;
@@ -419,21 +425,21 @@ PM_DEV void ref_window(float4* lw, TAP tap, const float (&spatial)[36], float tw
 }
 
 // stages the block's reference tile if it is to live in LDS and fills the pixel's weight column
-template <int SCALE, int BW, int BH>
+template <int SCALE, int BW, int BH, int NT = kBlockThreads, int TILE_MAX = 2048>
 PM_DEV void ref_window_of_pixel(const ProblemDev& P, int x, int y, int x0, int y0, bool valid, const float (&spatial)[36], float two_sc, RefWin& rw) {
-    typedef Win<SCALE, BW, BH> Wn;
+    typedef Win<SCALE, BW, BH, TILE_MAX> Wn;
     float4* lw = (float4*)pm_lds + threadIdx.x;
     if constexpr (Wn::tile_in_lds) {
-        load_ref_tile(P, pm_lds + kLdsWeightFloats, x0, y0, BW, BH, Wn::radius);
+        load_ref_tile<NT>(P, pm_lds + kLdsWeightFloatsOf<NT>, x0, y0, BW, BH, Wn::radius);
         __syncthreads();
         if (!valid) return;
-        const int ctr = kLdsWeightFloats + (y - y0 + Wn::radius) * Wn::pitch + (x - x0 + Wn::radius);
-        ref_window<SCALE>(lw, [&](int dx, int dy) { return pm_lds[ctr + dy * Wn::pitch + dx]; }, spatial, two_sc, rw);
+        const int ctr = kLdsWeightFloatsOf<NT> + (y - y0 + Wn::radius) * Wn::pitch + (x - x0 + Wn::radius);
+        ref_window<SCALE, NT>(lw, [&](int dx, int dy) { return pm_lds[ctr + dy * Wn::pitch + dx]; }, spatial, two_sc, rw);
     } else {
         if (!valid) return;
         const float* ctr = P.ref_img + (long)y * P.ref_pitch + x;
         const int pitch = P.ref_pitch;
-        ref_window<SCALE>(lw, [&](int dx, int dy) { return ctr[dy * pitch + dx]; }, spatial, two_sc, rw);
+        ref_window<SCALE, NT>(lw, [&](int dx, int dy) { return ctr[dy * pitch + dx]; }, spatial, two_sc, rw);
     }
 }
 
@@ -754,7 +760,7 @@ PM_DEV float ncc_core(const TEX& tex, float wf, float hf, float H0, float H1, fl
 }
 
 // one-thread-per-pixel kernels: wave-uniform source view (constants through the scalar cache)
-template <bool U8, int SCALE, bool DEEP = U8>
+template <bool U8, int SCALE, bool DEEP = U8, int NT = kBlockThreads>
 PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, float m0, float m1, float m2) {
     const float H0 = __builtin_fmaf(-vw.b[0], m0, vw.A[0]);
     const float H1 = __builtin_fmaf(-vw.b[0], m1, vw.A[1]);
@@ -771,7 +777,7 @@ PM_DEV float ncc_cost(const ViewDev& vw, const RefWin& rw, int px, int py, float
         else
             return make_src_tex(vw);
     }();
-    return ncc_core<U8, kBlockThreads, SCALE, DEEP>(tex, vw.wf, vw.hf, H0, H1, H2, H3, H4, H5, H6, H7, H8, rw, px, py);
+    return ncc_core<U8, NT, SCALE, DEEP>(tex, vw.wf, vw.hf, H0, H1, H2, H3, H4, H5, H6, H7, H8, rw, px, py);
 }
 
 // ---------------------------------------------------------------------------

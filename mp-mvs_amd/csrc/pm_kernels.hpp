@@ -79,10 +79,18 @@ constexpr int kWaveRows = U8 ? PM_WAVE_ROWS : PM_WAVE_ROWS_F32;
 #ifndef PM_BLOCK_WAVES_X
 #define PM_BLOCK_WAVES_X 1
 #endif
-template <bool U8>
-constexpr int kChkBlockW = 2 * (64 / kWaveRows<U8>) * PM_BLOCK_WAVES_X;
-template <bool U8>
-constexpr int kChkBlockH = (4 / PM_BLOCK_WAVES_X) * kWaveRows<U8>;
+// threads per block of the update kernel (a multiple of 64; the filter keeps 256)
+#ifndef PM_UPD_THREADS
+#define PM_UPD_THREADS 256
+#endif
+constexpr int kUpdThreads = PM_UPD_THREADS;
+static_assert(kUpdThreads % 64 == 0 && kUpdThreads >= 64 && kUpdThreads <= 256, "update blocks are 1 .. 4 waves");
+template <int NT>
+constexpr int kChkWavesX = (NT / 64 < PM_BLOCK_WAVES_X) ? NT / 64 : PM_BLOCK_WAVES_X;
+template <bool U8, int NT = 256>
+constexpr int kChkBlockW = 2 * (64 / kWaveRows<U8>) * kChkWavesX<NT>;
+template <bool U8, int NT = 256>
+constexpr int kChkBlockH = ((NT / 64) / kChkWavesX<NT>) * kWaveRows<U8>;
 
 // Blocks are dealt round-robin to the 8 XCDs (block b and b+8 share an L2):
 // renumber so that each XCD works through one contiguous run of the raster
@@ -94,17 +102,17 @@ PM_DEV int xcd_remap(int id, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-template <bool U8>
+template <bool U8, int NT = 256>
 PM_DEV bool checker_pixel(const ProblemDev& P, const LaunchArgs& a, int& x, int& y, int& x0, int& y0) {
     constexpr int kLanesPerRow = 64 / kWaveRows<U8>;
-    const int nbx = (P.W + kChkBlockW<U8> - 1) / kChkBlockW<U8>;
+    const int nbx = (P.W + kChkBlockW<U8, NT> - 1) / kChkBlockW<U8, NT>;
     const int b = xcd_remap(blockIdx.x, gridDim.x);
     const int by = b / nbx, bx = b - by * nbx;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    x0 = bx * kChkBlockW<U8>;
-    y0 = by * kChkBlockH<U8>;
-    y = y0 + (wv / PM_BLOCK_WAVES_X) * kWaveRows<U8> + lane / kLanesPerRow;
-    x = x0 + 2 * ((wv % PM_BLOCK_WAVES_X) * kLanesPerRow + lane % kLanesPerRow);
+    x0 = bx * kChkBlockW<U8, NT>;
+    y0 = by * kChkBlockH<U8, NT>;
+    y = y0 + (wv / kChkWavesX<NT>) * kWaveRows<U8> + lane / kLanesPerRow;
+    x = x0 + 2 * ((wv % kChkWavesX<NT>) * kLanesPerRow + lane % kLanesPerRow);
     x += (y + a.parity) & 1;
     return x < P.W && y < P.H && y < a.ylimit;
 }
@@ -132,9 +140,8 @@ inline size_t ncc_lds_bytes(int bw, int bh, int scale) {
 // The update kernel re-uses the tile region after its prologue as the exchange area of the compacted refinement (below):
 // 2 KB per wave, whether or not the tile itself is staged in LDS.  72 KB + 8 KB = half a CU's LDS: two blocks per CU as before.
 constexpr int kXchgBytesPerWave = 2048;
-constexpr int kLdsXchgFloats = 4 * kXchgBytesPerWave / 4;
-inline size_t update_lds_bytes() { return (size_t)(kLdsWeightFloats + kLdsXchgFloats) * sizeof(float); }
-static_assert(kLdsXchgFloats == 2048, "the exchange area takes the place of the largest LDS-resident reference tile (Win::tile_in_lds)");
+constexpr int kLdsXchgFloats = (kUpdThreads / 64) * kXchgBytesPerWave / 4;  // = the largest LDS-resident reference tile of the update kernel (Win::tile_in_lds)
+inline size_t update_lds_bytes() { return (size_t)(kLdsWeightFloatsOf<kUpdThreads> + kLdsXchgFloats) * sizeof(float); }
 
 // ---------------------------------------------------------------------------
 // InitializeScore, ref .cu:536-573 (+ :497-534)
@@ -239,13 +246,42 @@ PM_DEV float prior_term(float depth_diff, float angle_cos, float two_ds2, float 
         return prior_term_body(depth_diff, angle_cos, two_ds2, two_as2);
 }
 
+#ifdef PM_DBG_WAVETIME
+// Measurement builds only: every wave of the update kernel records when it started and ended (s_memrealtime, 100 MHz) and where it
+// ran (HW_ID: SIMD / CU / SH / SE, XCC_ID), 4 x u64 per wave at [launch % 16][block][wave]; tools/wave_timeline.py turns the
+// records of a launch into its slot occupancy over time.  The end stamp is written by every lane on its way out (the destructor
+// runs on each return path); the wave's stores retire in order, so the last lane to leave sets the value.
+struct WaveTimer {
+    unsigned long long* rec;
+    PM_DEV WaveTimer(unsigned long long* base, uint32_t launch) {
+        const unsigned wave = (unsigned)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+        const unsigned waves = gridDim.x * (blockDim.x >> 6);
+        rec = base + ((size_t)(launch & 15u) * waves + wave) * 4;
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        if ((threadIdx.x & 63) == 0) {
+            rec[0] = t;
+            rec[2] = ((unsigned long long)xcc << 32) | hw;
+            rec[3] = ((unsigned long long)blockIdx.x << 32) | (threadIdx.x >> 6);
+        }
+    }
+    PM_DEV ~WaveTimer() { rec[1] = __builtin_amdgcn_s_memrealtime(); }
+};
+#endif
+
 // ---------------------------------------------------------------------------
 // BlackPixelUpdate / RedPixelUpdate = CheckerboardPropagation +
 // PlaneHypothesisRefinement, ref .cu:724-998 and :642-722
 // ---------------------------------------------------------------------------
 template <bool GEOM, bool PRIOR, int MAXV, bool U8, int SCALE>
-__global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
+__global__ __launch_bounds__(kUpdThreads, kWavesPerSimd<U8>) void k_update(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
     const ProblemDev& P = *Pp;
+    constexpr int NT = kUpdThreads, BW = kChkBlockW<U8, NT>, BH = kChkBlockH<U8, NT>;
+#ifdef PM_DBG_WAVETIME
+    WaveTimer wave_timer(S.wavetime, a.launch);
+#endif
     // gathers of two window columns ahead (ncc_core): always with the 8-byte texels; with the 16-byte ones where the variant
     // still has the 24 registers of a third column (8 views; more views spill 4 .. 81 registers around the evaluations)
 #ifndef PM_F32_DEEP_WHEN
@@ -259,11 +295,11 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
     constexpr bool kPark = PM_PARK_WHEN;
 #endif
     int x, y, x0, y0;
-    const bool valid = checker_pixel<U8>(P, a, x, y, x0, y0);
+    const bool valid = checker_pixel<U8, NT>(P, a, x, y, x0, y0);
     RefWin rw;
-    ref_window_of_pixel<SCALE, kChkBlockW<U8>, kChkBlockH<U8>>(P, x, y, x0, y0, valid, a.spatial, a.two_sc, rw);
+    ref_window_of_pixel<SCALE, BW, BH, NT, kLdsXchgFloats>(P, x, y, x0, y0, valid, a.spatial, a.two_sc, rw);
     // the tile region becomes the exchange area of the refinement: every wave must be done reading the tile first
-    if constexpr (Win<SCALE, kChkBlockW<U8>, kChkBlockH<U8>>::tile_in_lds) __syncthreads();
+    if constexpr (Win<SCALE, BW, BH, kLdsXchgFloats>::tile_in_lds) __syncthreads();
     if (!valid) return;
     const int W = P.W, Hh = P.H, V = P.V;
     const int idx = y * W + x;
@@ -381,7 +417,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
             n0 = cand_m[nxt], n1 = cand_m[nxt + 1], n2 = cand_m[nxt + 2];
             float c;
             if ((flags >> slot) & 1u)
-                c = ncc_cost<U8, SCALE, kDeep>(P.views[v], rw, x, y, m0, m1, m2);
+                c = ncc_cost<U8, SCALE, kDeep, NT>(P.views[v], rw, x, y, m0, m1, m2);
             else
                 c = (slot == 0 && v == 0) ? 2.0f : 0.0f;  // `= {2.0f}` initialiser quirk, ref .cu:795
             cost_arr[PM_CIDX(slot * MAXV + v)] = c;
@@ -511,7 +547,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
             if (!(w > 0.0f)) continue;
             GeomCheck gc;
             if (GEOM) gc.issue(P.views[v], gz, x, y);  // the depth gather travels behind the NCC evaluation
-            const float c = ncc_cost<U8, SCALE, kDeep>(P.views[v], rw, x, y, m0, m1, m2);
+            const float c = ncc_cost<U8, SCALE, kDeep, NT>(P.views[v], rw, x, y, m0, m1, m2);
             if (GEOM) {
                 const float gt = 0.2f * gc.finish(P.views[v], x, y);
                 tc += w * (c + gt);
@@ -674,12 +710,12 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
     {
         constexpr int kLanesPerRow = 64 / kWaveRows<U8>;
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        char* const xw = reinterpret_cast<char*>(pm_lds + kLdsWeightFloats) + wv * kXchgBytesPerWave;
+        char* const xw = reinterpret_cast<char*>(pm_lds + kLdsWeightFloatsOf<NT>) + wv * kXchgBytesPerWave;
         float4* const x_rec = reinterpret_cast<float4*>(xw);                           // [64] plane of the item
         float2* const x_res = reinterpret_cast<float2*>(xw + 1024);                    // [64] (photometric cost, geometric term)
         unsigned short* const x_id = reinterpret_cast<unsigned short*>(xw + 1536);     // [64] owner lane
-        const int wave_y = y0 + (wv / PM_BLOCK_WAVES_X) * kWaveRows<U8>;
-        const int wave_x = x0 + 2 * (wv % PM_BLOCK_WAVES_X) * kLanesPerRow;
+        const int wave_y = y0 + (wv / kChkWavesX<NT>) * kWaveRows<U8>;
+        const int wave_x = x0 + 2 * (wv % kChkWavesX<NT>) * kLanesPerRow;
         // lanes without a pixel (image border) have left the kernel: the items of a round go to the lanes that are still here,
         // the r-th of them taking slot r
         const unsigned long long here = __ballot(1);
@@ -725,7 +761,7 @@ __global__ __launch_bounds__(256, kWavesPerSimd<U8>) void k_update(const Problem
                     plane_to_m(P, ipl, m0, m1, m2);
                     GeomCheck gc;
                     if (GEOM) gc.issue(P.views[v], depth_from_plane(P, ipl, ox, oy), ox, oy);
-                    const float c = ncc_cost<U8, SCALE, kDeep>(P.views[v], orw, ox, oy, m0, m1, m2);
+                    const float c = ncc_cost<U8, SCALE, kDeep, NT>(P.views[v], orw, ox, oy, m0, m1, m2);
                     float gt = 0.0f;
                     if (GEOM) gt = 0.2f * gc.finish(P.views[v], ox, oy);
                     x_res[rank] = make_float2(c, gt);

@@ -113,12 +113,23 @@ class HipPatchMatch(_abi.PatchMatchHandle):
         """pipelined Run() (mpmvs_run_get_async): returns at once; the maps reach the (pinned) arrays while the next such call
         of this context already runs -- give consecutive calls different arrays and collect with wait()"""
         assert planes.shape == (self.H, self.W, 4) and costs.shape == (self.H, self.W) and planes.dtype == np.float32 and costs.dtype == np.float32
+        for a in (planes, costs, geom):
+            # the copy engine writes into these arrays after this call has returned: they must be plain memory in C order ...
+            assert a is None or (a.flags.c_contiguous and a.flags.writeable), "run_into_async needs writeable C-contiguous arrays"
+        # ... and must stay alive until wait(): the handle keeps them (a caller that drops its last reference would otherwise
+        # let the DMA write into freed memory).  Pageable arrays work but make the copies synchronous: use alloc_pinned / pin_memory.
+        if not hasattr(self, "_async_bufs"):
+            self._async_bufs = []
+        self._async_bufs.append((planes, costs, geom))
         self._chk(self._f["run_get_async"](self._ctx, C.byref(params), int(seed), planes.ctypes.data, costs.ctypes.data,
                                            geom.ctypes.data if geom is not None else None), "run_get_async")
 
     def wait(self):
         """every pipelined Run() of this context has delivered its maps when this returns"""
-        self._chk(self._f["wait"](self._ctx), "wait")
+        try:
+            self._chk(self._f["wait"](self._ctx), "wait")
+        finally:
+            self._async_bufs = []
 
     def set_texture_format(self, force_fp32):
         """call before set_views; True keeps the fp32 texture format even for 8-bit exact images"""

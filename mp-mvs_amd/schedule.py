@@ -147,8 +147,24 @@ class SceneScheduler:
             for k, i in enumerate(self.owned):
                 self.handles[i].export_depth_device(mine[k].data_ptr())   # (2)
             if self.world > 1 or (self.force_collective and self.dist is not None):
+                import time
                 full = torch.empty((self.world * self.per_rank, self.H, self.W), dtype=torch.float32, device="cuda")
+                timed = isinstance(getattr(self, "timing", None), list)
+                if timed:
+                    # a timed run separates the wait for the slowest rank (a barrier) from the transfer itself, so that the
+                    # collective's time is a bandwidth figure and not this rank's lead over the others
+                    torch.cuda.synchronize()
+                    ta = time.perf_counter()
+                    self.dist.barrier()
+                    tb = time.perf_counter()
                 self.dist.all_gather_into_tensor(full, mine)
+                if timed:
+                    torch.cuda.synchronize()
+                    tc = time.perf_counter()
+                    recv = (self.world - 1) * mine.numel() * 4
+                    self.last_exchange = {"wait_for_slowest_rank_ms": round((tb - ta) * 1e3, 3), "all_gather_ms": round((tc - tb) * 1e3, 3),
+                                          "bytes_sent_per_rank": mine.numel() * 4, "bytes_received_per_rank": recv,
+                                          "received_GB_per_s": round(recv / max(tc - tb, 1e-9) / 1e9, 2)}
             else:
                 full = mine
             torch.cuda.synchronize()                      # (3)
@@ -185,10 +201,14 @@ class SceneScheduler:
         t0 = time.perf_counter()
         self.results = self._pass(fn)
         t1 = time.perf_counter()
+        self.last_exchange = None
         self._exchange()
         t2 = time.perf_counter()
         if isinstance(getattr(self, "timing", None), list):
-            self.timing.append({"pass": name, "compute_ms": round((t1 - t0) * 1e3, 2), "exchange_ms": round((t2 - t1) * 1e3, 2)})
+            rec = {"pass": name, "compute_ms": round((t1 - t0) * 1e3, 2), "exchange_ms": round((t2 - t1) * 1e3, 2)}
+            if self.last_exchange:
+                rec["collective"] = self.last_exchange
+            self.timing.append(rec)
 
     def fetch(self):
         """results of the last pass on the host: problem -> (planes, costs, geom costs)"""

@@ -1,7 +1,8 @@
 """BASELINE.json configs[2], [3] and [4] at their real size (1600x1200, 8 source views) inside the driver-run GPU suite.
 
-The oracle needs a minute per configuration at this size (tests/analysis/verify_cfg3_full.py keeps that comparison as a manual
-script), so these tests use what the domain offers independently of the size: the C++ ProcessProblem mirror on 8-bit textures
+The oracle needs a minute per configuration at this size: configs[3] -- the longest schedule, every mode -- is compared with it
+in full (test_cfg3_full_size_equals_the_oracle, round 5; until then the manual script tests/analysis/verify_cfg3_full.py), the
+other tests use what the domain offers independently of the size: the C++ ProcessProblem mirror on 8-bit textures
 with the device-built prior against the Python-driven schedule on fp32 textures with the host-built prior (two drivers, two
 texture formats, two prior implementations: one result, bit for bit), determinism for a seed, sensitivity to the seed, value
 ranges, unit normals facing the camera, convergence to the analytic ground truth; and for configs[4] the device-resident
@@ -66,6 +67,38 @@ def test_cfg2_cfg3_full_size(pm, engine, hostlib, scene, name, geom_iterations, 
     assert ((ncam * view).sum(-1) <= 1e-6).mean() > 0.999
     gt = v0.gt_depth
     assert (np.abs(depth - gt) / gt < 0.01).mean() > 0.97, name
+
+
+def test_cfg3_full_size_equals_the_oracle(pm, oracle, hostlib, scene):
+    """configs[3] at BASELINE size against the ORACLE (not a property): the shipped config.yaml schedule -- photometric 3 scales ->
+    geometric Run + planar prior + prior Run -> geometric Run, 228 hypothesis evaluations per pixel -- on one 1600x1200 Problem with
+    8 source views, through the C++ ProcessProblem mirror on the HIP path, against the same schedule driven on the CPU oracle:
+    depth, normal and cost maps bit for bit (about a minute of oracle time on 16 host threads)."""
+    sc, cams, imgs, src_depths = scene
+    seed = 4242
+    depth, normal, cost = hostlib.run_pipeline(0, cams, imgs, 2, 2, True, True, seed, src_depths)
+    planes, costs = oracle_pipeline(pm, oracle, hostlib, cams, imgs, src_depths, 2, 2, True, True, seed)
+    assert np.array_equal(depth, planes[..., 3]), f"{int((depth != planes[..., 3]).sum())} of {depth.size} depths differ"
+    assert np.array_equal(normal, planes[..., :3]) and np.array_equal(cost, costs)
+
+
+def test_cfg0_shape_on_the_hip_path(pm, oracle, engine):
+    """BASELINE.json configs[0] -- 2-view 320x240 pair, 3 PatchMatch iterations, photometric NCC only, single scale -- is the CPU
+    plumbing case by definition; the same shape on the HIP path equals the oracle bit for bit (planes, costs, selected views)."""
+    w, h = 320, 240
+    sc = pm.synth.make_problem_scene(w, h, n_src=1, quantize=True)
+    cams, imgs = sc.problem(0, [1])
+    dmin, dmax = pm.synth.kernel_depth_range(cams[0])
+    p = pm.PatchMatchParams(num_images=2, depth_min=float(dmin), depth_max=float(dmax), max_scale=0, max_iterations=3)
+    gpu, cpu = engine.create(0), oracle.create()
+    for hd in (gpu, cpu):
+        hd.set_views(cams, imgs)
+        hd.run(p, 12345)
+    (gp, gc), (cp, cc) = gpu.get(), cpu.get()
+    assert np.array_equal(gp, cp, equal_nan=True) and np.array_equal(gc, cc, equal_nan=True)
+    assert np.array_equal(gpu.get_selected_views(), cpu.get_selected_views())
+    gt = sc.views[0].gt_depth
+    assert (np.abs(gp[..., 3] - gt) / gt < 0.01).mean() > 0.5   # one source view, one scale: it converges on most of the image
 
 
 def test_cfg4_shipped_schedule_full_size_device_exchange(pm, engine):
