@@ -74,7 +74,16 @@ struct mpmvs_ctx {
     bool force_f32 = false;  // keep the fp32 texture format even for 8-bit exact images
     float k_ms[6] = {0, 0, 0, 0, 0, 0};
     int k_cnt[6] = {0, 0, 0, 0, 0, 0};
-    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;  // (kind, (start, stop))
+    struct Timed {
+        int kind;
+        hipEvent_t e0, e1;
+        int passes;  // update launches: passes chained into the launch (booked as that many launches, alternating colours)
+    };
+    std::vector<Timed> pending;
+    int* h_sync_err = nullptr;  // page-locked: the error word comes back with the stream synchronisation that ends a Run()
+    int* d_sync = nullptr;      // ticket / completion / error words of the chained update launches (pm_kernels.hpp, ChainArgs)
+    int sync_blocks = 0;
+    bool chain = true;          // Run() chains the passes of a scale into one launch (MPMVS_CHAIN=0: one launch per pass)
     std::vector<hipEvent_t> event_pool;
     std::string err;
 };
@@ -249,6 +258,8 @@ static void free_views(mpmvs_ctx* c) {
     if (c->S.sel) (void)pool_free(c->S.sel);
     if (c->S.geom) (void)pool_free(c->S.geom);
     if (c->S.depth) (void)pool_free(c->S.depth);
+    if (c->d_sync) (void)hipFree(c->d_sync);
+    c->d_sync = nullptr;
 #ifdef PM_DBG_WAVETIME
     if (c->S.wavetime) (void)hipFree(c->S.wavetime);
 #endif
@@ -559,6 +570,8 @@ mpmvs_ctx* mpmvs_create(int device) {
         return nullptr;
     }
     std::memset(&c->hP, 0, sizeof(ProblemDev));
+    if (hipHostMalloc(&c->h_sync_err, sizeof(int), hipHostMallocDefault) == hipSuccess) *c->h_sync_err = 0; else c->h_sync_err = nullptr;
+    if (const char* e = std::getenv("MPMVS_CHAIN")) c->chain = std::atoi(e) != 0;   // 0: one update launch per pass (measurements, bisecting)
     return c;
 }
 
@@ -575,6 +588,7 @@ void mpmvs_destroy(mpmvs_ctx* c) {
     if (c->staging_free) (void)hipEventDestroy(c->staging_free);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->h_sync_err) (void)hipHostFree(c->h_sync_err);
     delete c;
 }
 
@@ -753,6 +767,13 @@ static int set_views_impl(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const f
         hipMemsetAsync(c->S.sel, 0, wh * 4, c->stream) == hipSuccess && hipMemsetAsync(c->S.geom, 0, wh * 4, c->stream) == hipSuccess)
         rc = 0;
     c->depth_plane_valid = false;
+    if (!rc) {
+        // one completion word per update block (the smallest block the kernel can be built with is 16 x 8 pixels), zeroed once: every
+        // chained launch leaves them zeroed again
+        c->sync_blocks = ((c->W + 15) / 16 + 1) * ((c->H + 7) / 8 + 4);
+        const size_t bytes = (size_t)(kSyncHeader + c->sync_blocks) * sizeof(int);
+        if (hipMalloc(&c->d_sync, bytes) != hipSuccess || hipMemsetAsync(c->d_sync, 0, bytes, c->stream) != hipSuccess) rc = -100;
+    }
 #ifdef PM_DBG_WAVETIME
     // room for 16 launches of one wave per 64 pixels of a colour, 4 x u64 each (generous: blocks overhang the image border)
     if (!rc && (hipMalloc(&c->S.wavetime, kWaveTimeBytes(c->W, c->H)) != hipSuccess || hipMemsetAsync(c->S.wavetime, 0, kWaveTimeBytes(c->W, c->H), c->stream) != hipSuccess)) rc = -100;
@@ -967,39 +988,47 @@ static dim3 checker_grid(const mpmvs_ctx* c, const LaunchArgs& a) {
 // bound on the number of source views: buckets of 8 keep that scratch and the register pressure around it proportional to the
 // Problem (the shipped configuration allows 20 views, reference config/config.yaml:19; the hard limit is 32, ref .cu:500).
 template <bool GEOM, bool PRIOR, bool U8, int SCALE>
-static void launch_update3(mpmvs_ctx* c, const LaunchArgs& a) {
-    const dim3 grid = checker_grid<U8, kUpdThreads>(c, a);
-    const size_t lds = update_lds_bytes();
-    const dim3 blk(kUpdThreads);
+static void launch_update3(mpmvs_ctx* c, const LaunchArgs& a, const ChainArgs& ch0) {
+    constexpr int NT = kUpdThreads<U8, SCALE>, BW = kChkBlockW<U8, NT>, BH = kChkBlockH<U8, NT>;
+    const int rows = c->H < a.ylimit ? c->H : a.ylimit;
+    ChainArgs ch = ch0;
+    ch.nbx = (c->W + BW - 1) / BW;
+    ch.nby = (rows + BH - 1) / BH;
+    ch.nb = ch.nbx * ch.nby;
+    ch.sync = c->d_sync;
+    // every pass deals a multiple of 8 positions (chain_block): the blocks of all passes in one grid, pass-major
+    const dim3 grid((unsigned)(ch.n_pass * ((ch.nb + 7) & ~7)));
+    const size_t lds = update_lds_bytes<NT>();
+    const dim3 blk(NT);
     const int V = c->hP.V;
     if (V <= 8)
-        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 8, U8, SCALE>), grid, blk, lds, c->stream, c->dP, c->S, a);
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 8, U8, SCALE>), grid, blk, lds, c->stream, c->dP, c->S, a, ch);
     else if (V <= 16)
-        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 16, U8, SCALE>), grid, blk, lds, c->stream, c->dP, c->S, a);
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 16, U8, SCALE>), grid, blk, lds, c->stream, c->dP, c->S, a, ch);
     else if (V <= 24)
-        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 24, U8, SCALE>), grid, blk, lds, c->stream, c->dP, c->S, a);
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, 24, U8, SCALE>), grid, blk, lds, c->stream, c->dP, c->S, a, ch);
     else
-        hipLaunchKernelGGL((k_update<GEOM, PRIOR, kMaxViews, U8, SCALE>), grid, blk, lds, c->stream, c->dP, c->S, a);
+        hipLaunchKernelGGL((k_update<GEOM, PRIOR, kMaxViews, U8, SCALE>), grid, blk, lds, c->stream, c->dP, c->S, a, ch);
 }
 // The window scale is a template parameter of the NCC kernels (pm_device.hpp, Win).  The photometric update exists at the
 // scales 0..2 of the multi-scale schedule; the geometric and the prior update run at scale 0 only, as Run() does (ref
 // .cu:1188-1254: the scale loop belongs to the photometric branch).
 template <bool GEOM, bool PRIOR, bool U8>
-static void launch_update2(mpmvs_ctx* c, const LaunchArgs& a) {
+static void launch_update2(mpmvs_ctx* c, const LaunchArgs& a, const ChainArgs& ch) {
     if constexpr (GEOM || PRIOR) {
-        launch_update3<GEOM, PRIOR, U8, 0>(c, a);
+        launch_update3<GEOM, PRIOR, U8, 0>(c, a, ch);
     } else {
-        if (a.scale == 0) launch_update3<false, false, U8, 0>(c, a);
-        if (a.scale == 1) launch_update3<false, false, U8, 1>(c, a);
-        if (a.scale == 2) launch_update3<false, false, U8, 2>(c, a);
+        if (a.scale == 0) launch_update3<false, false, U8, 0>(c, a, ch);
+        if (a.scale == 1) launch_update3<false, false, U8, 1>(c, a, ch);
+        if (a.scale == 2) launch_update3<false, false, U8, 2>(c, a, ch);
     }
 }
 template <bool GEOM, bool PRIOR>
-static void launch_update(mpmvs_ctx* c, const LaunchArgs& a) {
+static void launch_update(mpmvs_ctx* c, const LaunchArgs& a, const ChainArgs& ch) {
     if (c->all_u8)
-        launch_update2<GEOM, PRIOR, true>(c, a);
+        launch_update2<GEOM, PRIOR, true>(c, a, ch);
     else
-        launch_update2<GEOM, PRIOR, false>(c, a);
+        launch_update2<GEOM, PRIOR, false>(c, a, ch);
 }
 
 // the spatial half of the bilateral weight exponent (ref .cu:318-323) of the 36 window taps at `scale`, [column][row]
@@ -1034,8 +1063,11 @@ static float host_exp_canonical(float x) {
     return out;
 }
 
-static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int kind, int iter, int scale, uint32_t launch) {
+// One launch.  For the update kinds `passes` > 1 chains that many passes into it -- alternating colours starting with `kind`, launch
+// ids launch, launch + 1, ..., iterations iter, iter (+1 after every red pass): exactly the launches that many calls would make.
+static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int kind, int iter, int scale, uint32_t launch, int passes = 1) {
     if (scale < 0 || scale > 2) return fail(c, -3, "scale must be 0..2");
+    if (passes < 1 || (passes + 1) / 2 + 1 > kChainMaxIters) return fail(c, -6, "too many passes in one update launch");
     if ((kind == MPMVS_KIND_BLACK || kind == MPMVS_KIND_RED) && scale != 0 && (p->geom_consistency || p->planar_prior))
         return fail(c, -3, "geometric / planar-prior updates run at scale 0 only (as Run() does)");
     LaunchArgs a;
@@ -1053,6 +1085,9 @@ static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int 
     fill_spatial_terms(a, scale);
     // ref .cu:832: double product, one rounding to float
     a.cost_threshold = (float)(0.8 * (double)host_exp_canonical((float)(iter * iter) / (-90.0f)));
+    ChainArgs ch{};
+    ch.n_pass = passes;
+    for (int j = 0; j < kChainMaxIters; ++j) ch.thr[j] = (float)(0.8 * (double)host_exp_canonical((float)((iter + j) * (iter + j)) / (-90.0f)));
     a.init_random = (!p->geom_consistency && !p->planar_prior) ? 1 : 0;
     a.use_prior = p->planar_prior ? 1 : 0;
 
@@ -1099,11 +1134,11 @@ static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int 
         case MPMVS_KIND_RED:
             c->depth_plane_valid = false;
             if (p->geom_consistency)
-                launch_update<true, false>(c, a);
+                launch_update<true, false>(c, a, ch);
             else if (p->planar_prior)
-                launch_update<false, true>(c, a);
+                launch_update<false, true>(c, a, ch);
             else
-                launch_update<false, false>(c, a);
+                launch_update<false, false>(c, a, ch);
             break;
         case MPMVS_KIND_DEPTH_NORMAL:
             hipLaunchKernelGGL(k_depth_normal, grid_dense, blk, 0, c->stream, c->dP, c->S);
@@ -1124,22 +1159,40 @@ static int enqueue_step(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, int 
     HIPCHK(c, hipGetLastError());
     if (c->profiling) {
         HIPCHK(c, hipEventRecord(e1, c->stream));
-        c->pending.push_back({kind, {e0, e1}});
+        c->pending.push_back({kind, e0, e1, passes});
     }
     return 0;
 }
 
 static int finish(mpmvs_ctx* c) {
+    // the error word of the chained update launches: a block that gave up waiting for its neighbours (pm_kernels.hpp, kSpinLimit)
+    const bool check = c->d_sync && c->h_sync_err;
+    if (check) HIPCHK(c, hipMemcpyAsync(c->h_sync_err, c->d_sync + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (auto& pe : c->pending) {
         float ms = 0.0f;
-        (void)hipEventElapsedTime(&ms, pe.second.first, pe.second.second);
-        c->k_ms[pe.first] += ms;
-        c->k_cnt[pe.first] += 1;
-        c->event_pool.push_back(pe.second.first);
-        c->event_pool.push_back(pe.second.second);
+        (void)hipEventElapsedTime(&ms, pe.e0, pe.e1);
+        if (pe.passes > 1) {
+            // a chained update launch: booked as its passes, alternating colours from pe.kind on, each with an equal share of the time
+            const int other = pe.kind == MPMVS_KIND_BLACK ? MPMVS_KIND_RED : MPMVS_KIND_BLACK;
+            const int n_first = (pe.passes + 1) / 2, n_other = pe.passes / 2;
+            c->k_ms[pe.kind] += ms * (float)n_first / (float)pe.passes;
+            c->k_ms[other] += ms * (float)n_other / (float)pe.passes;
+            c->k_cnt[pe.kind] += n_first;
+            c->k_cnt[other] += n_other;
+        } else {
+            c->k_ms[pe.kind] += ms;
+            c->k_cnt[pe.kind] += 1;
+        }
+        c->event_pool.push_back(pe.e0);
+        c->event_pool.push_back(pe.e1);
     }
     c->pending.clear();
+    if (check && *c->h_sync_err) {
+        (void)hipMemsetAsync(c->d_sync, 0, (size_t)(kSyncHeader + c->sync_blocks) * sizeof(int), c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        return fail(c, -101, "an update launch timed out waiting for the blocks of its previous pass (results invalid)");
+    }
     return 0;
 }
 
@@ -1153,10 +1206,14 @@ static int abandon_run(mpmvs_ctx* c, int rc) {
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     (void)hipStreamSynchronize(c->stream);
     for (auto& pe : c->pending) {
-        c->event_pool.push_back(pe.second.first);
-        c->event_pool.push_back(pe.second.second);
+        c->event_pool.push_back(pe.e0);
+        c->event_pool.push_back(pe.e1);
     }
     c->pending.clear();
+    if (c->d_sync) {  // a launch that did not finish leaves them dirty
+        (void)hipMemsetAsync(c->d_sync, 0, (size_t)(kSyncHeader + c->sync_blocks) * sizeof(int), c->stream);
+        (void)hipStreamSynchronize(c->stream);
+    }
     (void)hipGetLastError();
     c->err = why;
     return rc;
@@ -1169,17 +1226,29 @@ static int abandon_run(mpmvs_ctx* c, int rc) {
 static int enqueue_updates(mpmvs_ctx* c, const mpmvs_params* p, uint64_t seed, uint32_t& launch) {
     int rc;
     if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_INIT, 0, p->max_scale, launch++))) return rc;
-    if (p->geom_consistency || p->planar_prior) {
-        for (int i = 0; i < p->max_iterations; ++i) {
-            if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_BLACK, i, 0, launch++))) return rc;
-            if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_RED, i, 0, launch++))) return rc;
-        }
-    } else {
-        for (int s = p->max_scale; s >= 0; --s)
-            for (int i = 0; i < p->max_iterations; ++i) {
+    // the black / red passes of one window scale: one launch per pass (the reference's schedule, ref .cu:1211-1236), or -- the
+    // default -- chained into launches of up to 2 * (kChainMaxIters - 1) passes whose blocks wait for their neighbours of the pass
+    // before (pm_kernels.hpp, k_update): same launch ids, same results, no tail between the passes
+    auto scale_passes = [&](int s) -> int {
+        int i = 0;
+        while (i < p->max_iterations) {
+            const int n = c->chain ? std::min(p->max_iterations - i, kChainMaxIters - 1) : 1;
+            if (c->chain) {
+                if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_BLACK, i, s, launch, 2 * n))) return rc;
+                launch += 2 * n;
+            } else {
                 if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_BLACK, i, s, launch++))) return rc;
                 if ((rc = enqueue_step(c, p, seed, MPMVS_KIND_RED, i, s, launch++))) return rc;
             }
+            i += n;
+        }
+        return 0;
+    };
+    if (p->geom_consistency || p->planar_prior) {
+        if ((rc = scale_passes(0))) return rc;
+    } else {
+        for (int s = p->max_scale; s >= 0; --s)
+            if ((rc = scale_passes(s))) return rc;
     }
     return 0;
 }

@@ -79,12 +79,19 @@ constexpr int kWaveRows = U8 ? PM_WAVE_ROWS : PM_WAVE_ROWS_F32;
 #ifndef PM_BLOCK_WAVES_X
 #define PM_BLOCK_WAVES_X 1
 #endif
-// threads per block of the update kernel (a multiple of 64; the filter keeps 256)
-#ifndef PM_UPD_THREADS
-#define PM_UPD_THREADS 256
-#endif
+// Threads per block of the update kernel, per variant (the filter keeps 256).  Chained launches (k_update) made small blocks pay
+// where the taps of a wave stay close together: a one-wave block holds no LDS for slower siblings and fills freed slots wave by
+// wave -- fp16 texels at window scale 0: 2.47 against 2.53 ms per pass (photometric; geometric -1.4 %, prior -1.8 %).  Everywhere
+// else the four waves of a 16 x 32 block share lines in the L1 that four unrelated one-wave blocks do not: scale 1 +3.7 %, scale 2
+// +34 %, fp32 texels +5 ... +60 % (round 5, 1600x1200, 8 views, tools/bench_scales.py).  PM_UPD_THREADS: one size everywhere
+// (measurement builds).
+#ifdef PM_UPD_THREADS
+template <bool U8, int SCALE>
 constexpr int kUpdThreads = PM_UPD_THREADS;
-static_assert(kUpdThreads % 64 == 0 && kUpdThreads >= 64 && kUpdThreads <= 256, "update blocks are 1 .. 4 waves");
+#else
+template <bool U8, int SCALE>
+constexpr int kUpdThreads = (U8 && SCALE == 0) ? 64 : 256;
+#endif
 template <int NT>
 constexpr int kChkWavesX = (NT / 64 < PM_BLOCK_WAVES_X) ? NT / 64 : PM_BLOCK_WAVES_X;
 template <bool U8, int NT = 256>
@@ -102,18 +109,19 @@ PM_DEV int xcd_remap(int id, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// b: the block's position in raster order over the image (the launch decides which block takes which position: xcd_remap for
+// the plain launches, the chained update kernel's ticket order)
 template <bool U8, int NT = 256>
-PM_DEV bool checker_pixel(const ProblemDev& P, const LaunchArgs& a, int& x, int& y, int& x0, int& y0) {
+PM_DEV bool checker_pixel(const ProblemDev& P, const LaunchArgs& a, int b, int parity, int& x, int& y, int& x0, int& y0) {
     constexpr int kLanesPerRow = 64 / kWaveRows<U8>;
     const int nbx = (P.W + kChkBlockW<U8, NT> - 1) / kChkBlockW<U8, NT>;
-    const int b = xcd_remap(blockIdx.x, gridDim.x);
     const int by = b / nbx, bx = b - by * nbx;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     x0 = bx * kChkBlockW<U8, NT>;
     y0 = by * kChkBlockH<U8, NT>;
     y = y0 + (wv / kChkWavesX<NT>) * kWaveRows<U8> + lane / kLanesPerRow;
     x = x0 + 2 * ((wv % kChkWavesX<NT>) * kLanesPerRow + lane % kLanesPerRow);
-    x += (y + a.parity) & 1;
+    x += (y + parity) & 1;
     return x < P.W && y < P.H && y < a.ylimit;
 }
 // all-pixel launches: wave = 8x8 patch, block = 16x16
@@ -140,8 +148,10 @@ inline size_t ncc_lds_bytes(int bw, int bh, int scale) {
 // The update kernel re-uses the tile region after its prologue as the exchange area of the compacted refinement (below):
 // 2 KB per wave, whether or not the tile itself is staged in LDS.  72 KB + 8 KB = half a CU's LDS: two blocks per CU as before.
 constexpr int kXchgBytesPerWave = 2048;
-constexpr int kLdsXchgFloats = (kUpdThreads / 64) * kXchgBytesPerWave / 4;  // = the largest LDS-resident reference tile of the update kernel (Win::tile_in_lds)
-inline size_t update_lds_bytes() { return (size_t)(kLdsWeightFloatsOf<kUpdThreads> + kLdsXchgFloats) * sizeof(float); }
+template <int NT>
+constexpr int kLdsXchgFloats = (NT / 64) * kXchgBytesPerWave / 4;  // = the largest LDS-resident reference tile of the update kernel (Win::tile_in_lds)
+template <int NT>
+inline size_t update_lds_bytes() { return (size_t)(kLdsWeightFloatsOf<NT> + kLdsXchgFloats<NT>) * sizeof(float); }
 
 // ---------------------------------------------------------------------------
 // InitializeScore, ref .cu:536-573 (+ :497-534)
@@ -229,6 +239,17 @@ PM_DEV int pinned_here(int i) {
     return i;
 }
 
+// Write-through stores (sc0 sc1) of the per-pixel results: the bytes go to memory at once instead of waiting in the XCD's L2, so
+// that a block on ANOTHER XCD can read them within the same launch once the storing wave has waited for them (s_waitcnt vmcnt(0))
+// and signalled (k_update below).  Inline asm: hipcc has no 16-byte store with cache-policy bits; the compiler's own vmcnt
+// bookkeeping stays conservative with an extra store in flight, and k_update drains the counter itself before it signals.
+PM_DEV void st_f32x4_wt(float4* p, const float4 v) {
+    const f32x4q d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(d) : "memory");
+}
+PM_DEV void st_f32_wt(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory"); }
+PM_DEV void st_u32_wt(uint32_t* p, uint32_t v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory"); }
+
 PM_DEV float prior_term_body(float depth_diff, float angle_cos, float two_ds2, float two_as2) {
     const float ad = d_acos(angle_cos);
     return 0.5f + d_exp(-depth_diff * depth_diff / two_ds2) * d_exp(-ad * ad / two_as2);
@@ -247,27 +268,29 @@ PM_DEV float prior_term(float depth_diff, float angle_cos, float two_ds2, float 
 }
 
 #ifdef PM_DBG_WAVETIME
-// Measurement builds only: every wave of the update kernel records when it started and ended (s_memrealtime, 100 MHz) and where it
-// ran (HW_ID: SIMD / CU / SH / SE, XCC_ID), 4 x u64 per wave at [launch % 16][block][wave]; tools/wave_timeline.py turns the
-// records of a launch into its slot occupancy over time.  The end stamp is written by every lane on its way out (the destructor
-// runs on each return path); the wave's stores retire in order, so the last lane to leave sets the value.
+// Measurement builds only: every wave of the update kernel records when it entered the kernel, when its block's dependencies were met
+// and when it ended (s_memrealtime, 100 MHz) and where it ran (HW_ID: SIMD / CU / SH / SE, XCC_ID), 4 x u64 per wave at
+// [launch id % 16][raster block][wave]; tools/wave_timeline.py turns the records into the slot occupancy over time.
 struct WaveTimer {
-    unsigned long long* rec;
-    PM_DEV WaveTimer(unsigned long long* base, uint32_t launch) {
-        const unsigned wave = (unsigned)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-        const unsigned waves = gridDim.x * (blockDim.x >> 6);
-        rec = base + ((size_t)(launch & 15u) * waves + wave) * 4;
+    unsigned long long t_enter, t_ready;
+    PM_DEV WaveTimer() { t_enter = t_ready = __builtin_amdgcn_s_memrealtime(); }
+    PM_DEV void ready() { t_ready = __builtin_amdgcn_s_memrealtime(); }   // the block's dependencies are met: the update itself starts
+    PM_DEV void finish(unsigned long long* base, uint32_t launch, int b, int n_blocks) const {
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
         uint32_t hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
-        if ((threadIdx.x & 63) == 0) {
-            rec[0] = t;
-            rec[2] = ((unsigned long long)xcc << 32) | hw;
-            rec[3] = ((unsigned long long)blockIdx.x << 32) | (threadIdx.x >> 6);
+        if ((threadIdx.x & 63) == 0 && b >= 0) {
+            const unsigned waves = (unsigned)n_blocks * (blockDim.x >> 6);
+            unsigned long long* rec = base + ((size_t)(launch & 15u) * waves + (unsigned)b * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4;
+            rec[0] = t_enter;
+            rec[1] = t_end;
+            rec[2] = ((unsigned long long)(xcc & 0xfu) << 32) | hw;
+            unsigned long long waited = t_ready - t_enter;   // ticks of 10 ns between kernel entry and the start of the update (ticket, wait for the neighbours, barriers)
+            waited = waited > 0xffffffull ? 0xffffffull : waited;
+            rec[3] = ((unsigned long long)(unsigned)b << 32) | (waited << 8) | (threadIdx.x >> 6);
         }
     }
-    PM_DEV ~WaveTimer() { rec[1] = __builtin_amdgcn_s_memrealtime(); }
 };
 #endif
 
@@ -275,13 +298,12 @@ struct WaveTimer {
 // BlackPixelUpdate / RedPixelUpdate = CheckerboardPropagation +
 // PlaneHypothesisRefinement, ref .cu:724-998 and :642-722
 // ---------------------------------------------------------------------------
+// One pixel update of one block: `b` is the block's raster position, `parity` the colour of this pass, `launch` its launch id (the
+// key of the random streams), `thr` the view-selection threshold of its iteration (ref .cu:832).  The results leave through
+// write-through stores (st_*_wt): what the chained launch below hands from one pass to the next.
 template <bool GEOM, bool PRIOR, int MAXV, bool U8, int SCALE>
-__global__ __launch_bounds__(kUpdThreads, kWavesPerSimd<U8>) void k_update(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
-    const ProblemDev& P = *Pp;
-    constexpr int NT = kUpdThreads, BW = kChkBlockW<U8, NT>, BH = kChkBlockH<U8, NT>;
-#ifdef PM_DBG_WAVETIME
-    WaveTimer wave_timer(S.wavetime, a.launch);
-#endif
+PM_DEV void update_body(const ProblemDev& P, const StateDev& S, const LaunchArgs& a, int b, int parity, uint32_t launch, float thr) {
+    constexpr int NT = kUpdThreads<U8, SCALE>, BW = kChkBlockW<U8, NT>, BH = kChkBlockH<U8, NT>;
     // gathers of two window columns ahead (ncc_core): always with the 8-byte texels; with the 16-byte ones where the variant
     // still has the 24 registers of a third column (8 views; more views spill 4 .. 81 registers around the evaluations)
 #ifndef PM_F32_DEEP_WHEN
@@ -295,15 +317,15 @@ __global__ __launch_bounds__(kUpdThreads, kWavesPerSimd<U8>) void k_update(const
     constexpr bool kPark = PM_PARK_WHEN;
 #endif
     int x, y, x0, y0;
-    const bool valid = checker_pixel<U8, NT>(P, a, x, y, x0, y0);
+    const bool valid = checker_pixel<U8, NT>(P, a, b, parity, x, y, x0, y0);
     RefWin rw;
-    ref_window_of_pixel<SCALE, BW, BH, NT, kLdsXchgFloats>(P, x, y, x0, y0, valid, a.spatial, a.two_sc, rw);
+    ref_window_of_pixel<SCALE, BW, BH, NT, kLdsXchgFloats<NT>>(P, x, y, x0, y0, valid, a.spatial, a.two_sc, rw);
     // the tile region becomes the exchange area of the refinement: every wave must be done reading the tile first
-    if constexpr (Win<SCALE, BW, BH, kLdsXchgFloats>::tile_in_lds) __syncthreads();
+    if constexpr (Win<SCALE, BW, BH, kLdsXchgFloats<NT>>::tile_in_lds) __syncthreads();
     if (!valid) return;
     const int W = P.W, Hh = P.H, V = P.V;
     const int idx = y * W + x;
-    Rng g = rng_make(a.seed, (uint32_t)idx, a.launch);
+    Rng g = rng_make(a.seed, (uint32_t)idx, launch);
 
     // -- 8 sampling regions: position of the lowest stored cost (ref .cu:798-816)
     int pos[8];
@@ -359,7 +381,6 @@ __global__ __launch_bounds__(kUpdThreads, kWavesPerSimd<U8>) void k_update(const
     // every entry is zeroed as in ref .cu:821: the refinement's geometric term
     // reads view_w[candidate 0..4], beyond V when V < 5 (ref .cu:689)
     for (int v = 0; v < MAXV; ++v) view_w[v] = 0.0f;
-    const float thr = a.cost_threshold;  // ref .cu:832, formed on the host (LaunchArgs)
 
     // the pixel's current plane is read where it is needed (phase B) instead of being carried through phase A
     const float depth_sigma = (a.depth_max - a.depth_min) / 64.0f;
@@ -598,7 +619,7 @@ __global__ __launch_bounds__(kUpdThreads, kWavesPerSimd<U8>) void k_update(const
                     // ref .cu:950/961: the shadowed depth_now keeps the old plane's depth
                     plane_now = cpl;
                     restricted_cost = rfc[max_idx];
-                    S.sel[idx_a] = temp_sel;
+                    st_u32_wt(&S.sel[idx_a], temp_sel);
                 }
             }
         } else if ((flags >> min_idx) & 1u) {
@@ -617,7 +638,7 @@ __global__ __launch_bounds__(kUpdThreads, kWavesPerSimd<U8>) void k_update(const
             depth_now = db;
             plane_now = cpl;
             cost_now = final_costs[min_idx];
-            S.sel[idx_a] = temp_sel;
+            st_u32_wt(&S.sel[idx_a], temp_sel);
         }
     }
     // ---- refinement candidates (ref .cu:644-675)
@@ -756,7 +777,7 @@ __global__ __launch_bounds__(kUpdThreads, kWavesPerSimd<U8>) void k_update(const
                 orw.var_r = __int_as_float(__builtin_amdgcn_ds_bpermute(owner << 2, __float_as_int(rw.var_r)));
                 if (have) {
                     const int oy = wave_y + owner / kLanesPerRow;
-                    const int ox = wave_x + 2 * (owner % kLanesPerRow) + ((oy + a.parity) & 1);
+                    const int ox = wave_x + 2 * (owner % kLanesPerRow) + ((oy + parity) & 1);
                     float m0, m1, m2;
                     plane_to_m(P, ipl, m0, m1, m2);
                     GeomCheck gc;
@@ -808,9 +829,134 @@ __global__ __launch_bounds__(kUpdThreads, kWavesPerSimd<U8>) void k_update(const
         }
     }
     const int idx_o = pinned_here(idx);
-    S.costs[idx_o] = cost_now;
-    S.planes[idx_o] = plane_now;
-    if (GEOM) S.geom[idx_o] = geom_now;
+    st_f32_wt(&S.costs[idx_o], cost_now);
+    st_f32x4_wt(&S.planes[idx_o], plane_now);
+    if (GEOM) st_f32_wt(&S.geom[idx_o], geom_now);
+}
+
+// ---------------------------------------------------------------------------
+// The update LAUNCH: several passes (black, red, black, ...) of one window scale in ONE launch (round 5).
+//
+// Launched one pass at a time, every pass ends in a tail: once its last block has started, wave slots run empty while the
+// slowest blocks finish -- 7.5-9 % of the slot-time of a 1600x1200 launch (profiles/r05_wave_timeline.txt; a wave lives ~300 us,
+// 1/8 of the launch).  But a block of pass p + 1 needs only the blocks of pass p within the reach of the candidate search (23 px,
+// kDirs): here the grid holds the blocks of ALL passes, each block takes a ticket (pass-major), waits until the blocks around it
+// have completed the pass before, and runs; the tail of pass p fills with the head of pass p + 1, and only the last pass of the
+// launch has a tail.  Correctness does not depend on placement or dispatch order:
+//   * tickets: a block that holds ticket t knows that every ticket < t is held by a block that has started, so whatever it
+//     waits for is running or done -- no deadlock however the hardware orders the blocks (and every wait is bounded: after
+//     kSpinLimit polls a block raises the launch's error word, which ends all waits; the host reports -101);
+//   * hand-over (MI355X_MICROARCH.md, "inter-workgroup visibility"): results leave through write-through stores (sc0 sc1); each
+//     wave waits for its stores (s_waitcnt vmcnt(0)) and then adds 1 to its block's completion counter (agent-scope atomic);
+//     the consumer polls the counters of the blocks in reach with relaxed sc1 loads, then ONE agent-scope acquire
+//     (invalidates the CU's L1), waits for it, and a workgroup barrier stands between that and every load of the block;
+//   * read-after-write and write-after-read are the same condition: block B of pass p + 1 overwrites pixels of its colour that
+//     the blocks of pass p around it read (as candidates) until they END -- B waits for exactly those blocks.
+// Order: each XCD works through one horizontal band of the image (xcd_remap: L2 locality), EVEN bands top-down and ODD bands
+// bottom-up, every pass alike.  Neighbouring bands then reach their common border at about the same time -- both early or both
+// late in the pass -- so that the first blocks of the next pass find the blocks across the border done.  (Top-down everywhere,
+// the first blocks of a band would wait for the LAST blocks of the band above: no overlap at all.)
+// The sync words live in global memory: [0] ticket, [1] waves finished, [2] error, [16 + b] waves of block b that have completed
+// (monotonic over the passes).  The last wave to finish zeroes them for the next launch.
+// ---------------------------------------------------------------------------
+struct ChainArgs {
+    int n_pass;    // passes in this launch; pass k has colour (a.parity + k) & 1, launch id a.launch + k, iteration a.iter + (a.parity + k) / 2
+    int nb;        // blocks per pass, nbx per row of blocks, nby rows
+    int nbx, nby;
+    float thr[8];  // view-selection threshold (ref .cu:832) of the iterations a.iter, a.iter + 1, ...
+    int* sync;
+};
+constexpr int kChainMaxIters = 8;
+constexpr int kSyncHeader = 16;
+constexpr int kSpinLimit = 1 << 20;   // polls of ~1-2 us each: seconds, three orders of magnitude above any legitimate wait
+
+// position v of the pass-major order -> raster block (or -1: padding, the order is padded to a multiple of 8 so that every
+// pass deals its blocks to the XCDs alike).  v & 7 = the XCD under round-robin placement; band j is reversed for odd j.
+PM_DEV int chain_block(int v, int nb) {
+    const int q = nb >> 3, r = nb & 7, j = v & 7, k = v >> 3;
+    const int len = q + (j < r ? 1 : 0);
+    if (k >= len) return -1;
+    const int start = j < r ? j * (q + 1) : r * (q + 1) + (j - r) * q;
+    return (j & 1) ? start + len - 1 - k : start + k;
+}
+
+template <bool GEOM, bool PRIOR, int MAXV, bool U8, int SCALE>
+__global__ __launch_bounds__((kUpdThreads<U8, SCALE>), kWavesPerSimd<U8>) void k_update(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a, ChainArgs ch) {
+    const ProblemDev& P = *Pp;
+    constexpr int NT = kUpdThreads<U8, SCALE>, BW = kChkBlockW<U8, NT>, BH = kChkBlockH<U8, NT>, kWaves = NT / 64;
+    static_assert(NT % 64 == 0 && NT >= 64 && NT <= 256, "update blocks are 1 .. 4 waves");
+    constexpr int RX = (23 + BW - 1) / BW, RY = (23 + BH - 1) / BH, NN = (2 * RX + 1) * (2 * RY + 1);  // blocks within the 23 px of kDirs
+    static_assert(NN <= 64, "one lane polls one neighbour");
+#ifdef PM_DBG_WAVETIME
+    WaveTimer wave_timer;
+#endif
+    // two spare words of wave 0's exchange area (the tile / exchange region is not in use yet; two barriers fence the hand-over)
+    int* const bcast = reinterpret_cast<int*>(reinterpret_cast<char*>(pm_lds + kLdsWeightFloatsOf<NT>) + 1664);
+    if (threadIdx.x < 64) {
+        int t = 0;
+        if (threadIdx.x == 0) t = __hip_atomic_fetch_add(&ch.sync[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = __builtin_amdgcn_readfirstlane(t);
+        const int n8 = (ch.nb + 7) & ~7;
+        const int pass = t / n8;
+        const int b = chain_block(t - pass * n8, ch.nb);
+        if (b >= 0 && pass > 0) {
+            const int by = b / ch.nbx, bx = b - by * ch.nbx;
+            int nbid = -1;
+            if ((int)threadIdx.x < NN) {
+                const int x = bx + (int)threadIdx.x % (2 * RX + 1) - RX, y = by + (int)threadIdx.x / (2 * RX + 1) - RY;
+                if (x >= 0 && x < ch.nbx && y >= 0 && y < ch.nby) nbid = y * ch.nbx + x;
+            }
+            const int need = pass * kWaves;
+            for (int spins = 0;; ++spins) {
+                int d = need;
+                if (nbid >= 0) d = __hip_atomic_load(&ch.sync[kSyncHeader + nbid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(d >= need)) break;
+                __builtin_amdgcn_s_sleep(8);
+                if ((spins & 255) == 255) {
+                    const bool give_up = spins >= kSpinLimit || __hip_atomic_load(&ch.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                    if (__builtin_amdgcn_readfirstlane((int)give_up)) {
+                        if (threadIdx.x == 0) __hip_atomic_store(&ch.sync[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (threadIdx.x == 0) {
+            bcast[0] = pass;
+            bcast[1] = b;
+        }
+    }
+    __syncthreads();
+    const int pass = __builtin_amdgcn_readfirstlane(bcast[0]), b = __builtin_amdgcn_readfirstlane(bcast[1]);
+    __syncthreads();
+#ifdef PM_DBG_WAVETIME
+    wave_timer.ready();
+#endif
+    if (b >= 0) {
+        const int k = a.parity + pass;
+        update_body<GEOM, PRIOR, MAXV, U8, SCALE>(P, S, a, b, k & 1, a.launch + (uint32_t)pass, ch.thr[(k >> 1) < kChainMaxIters ? (k >> 1) : 0]);
+    }
+    // completion: this wave's stores have left (write-through) before it counts itself done
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef PM_DBG_WAVETIME
+    wave_timer.finish(S.wavetime, a.launch + (uint32_t)pass, b, ch.nb);
+#endif
+    int fin = 0;
+    if ((threadIdx.x & 63) == 0) {
+        if (b >= 0) __hip_atomic_fetch_add(&ch.sync[kSyncHeader + b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fin = __hip_atomic_fetch_add(&ch.sync[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    fin = __builtin_amdgcn_readfirstlane(fin);
+    if (fin == (int)gridDim.x * kWaves - 1) {
+        // the last wave of the launch: nobody polls any more; leave the words zeroed for the next launch (the error word stays)
+        for (int i = threadIdx.x & 63; i < ch.nb; i += 64) ch.sync[kSyncHeader + i] = 0;
+        if ((threadIdx.x & 63) == 0) {
+            ch.sync[0] = 0;
+            ch.sync[1] = 0;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -881,7 +1027,7 @@ PM_DEV float median21_rounds(float (&v)[21], float& lowest) {
 __global__ __launch_bounds__(256) void k_filter(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a) {
     const ProblemDev& P = *Pp;
     int x, y, x0, y0;
-    if (!checker_pixel<true>(P, a, x, y, x0, y0)) return;  // the filter has no texture: any shape
+    if (!checker_pixel<true>(P, a, xcd_remap(blockIdx.x, gridDim.x), a.parity, x, y, x0, y0)) return;  // the filter has no texture: any shape
     const int W = P.W, Hh = P.H;
     const int ctr = y * W + x;
     if (S.costs[ctr] < 0.001f) return;

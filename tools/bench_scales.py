@@ -12,6 +12,8 @@ sc = pm.synth.make_problem_scene(W, H, n_src=V, quantize=True)
 cams, imgs = sc.problem(0, list(range(1, V + 1)))
 dmin, dmax = pm.synth.kernel_depth_range(cams[0])
 h = engine.create(0)
+if os.environ.get("MPMVS_FORCE_F32"):   # the fp32 texture format on the same 8-bit images
+    h.set_texture_format(True)
 h.set_views(cams, imgs)
 h.set_profiling(True)
 p = pm.PatchMatchParams(num_images=V + 1, depth_min=float(dmin), depth_max=float(dmax), max_scale=2)

@@ -37,6 +37,7 @@ def analyse(rec, waves_per_block, out):
     start, end = rec[:, 0].astype(np.int64), rec[:, 1].astype(np.int64)
     hw, xcc = (rec[:, 2] & 0xffffffff).astype(np.int64), (rec[:, 2] >> 32).astype(np.int64) & 0xf
     block = (rec[:, 3] >> 32).astype(np.int64)
+    waited = ((rec[:, 3] >> 8) & 0xffffff).astype(np.float64)   # ticks between kernel entry and the start of the update itself
     t0, t1 = start.min(), end.max()
     span = float(t1 - t0)
     cu = (hw >> 8) & 0xf
@@ -88,6 +89,9 @@ def analyse(rec, waves_per_block, out):
                f"ramp {(ramp_end - t0) * TICK_NS / 1e3:.1f} us")
     out.append(f"  wave duration: mean {dur.mean() * TICK_NS / 1e3:.1f} us, p5 {np.percentile(dur, 5) * TICK_NS / 1e3:.1f}, p50 {np.percentile(dur, 50) * TICK_NS / 1e3:.1f}, "
                f"p95 {np.percentile(dur, 95) * TICK_NS / 1e3:.1f}, max {dur.max() * TICK_NS / 1e3:.1f}")
+    out.append(f"  kernel entry -> start of the update (ticket, wait for the neighbouring blocks of the pass before, barriers): mean {waited.mean() * TICK_NS / 1e3:.2f} us, "
+               f"p50 {np.percentile(waited, 50) * TICK_NS / 1e3:.2f}, p95 {np.percentile(waited, 95) * TICK_NS / 1e3:.2f}, max {waited.max() * TICK_NS / 1e3:.1f}; "
+               f"{100.0 * waited.sum() / (span * slots):.2f} % of the launch's slot-time")
     full = b_cnt == waves_per_block
     if waves_per_block > 1 and full.any():
         # slowest wave of a block against the mean of its waves
@@ -126,7 +130,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--size", default="1600x1200")
-    ap.add_argument("--threads", type=int, default=256, help="threads per update block of the library in use (PM_UPD_THREADS)")
+    ap.add_argument("--threads", type=int, default=64, help="threads per update block of the library in use (PM_UPD_THREADS)")
     args = ap.parse_args()
     sys.argv = [sys.argv[0]]
     import bench
@@ -156,13 +160,24 @@ def main():
     waves = nblocks * wpb
     out = [f"# wave timeline of the update launches of one cfg-1 Run() ({w}x{h}, 8 views, photometric, 3 iterations); library {os.environ.get('MPMVS_HIP_LIB', 'default')}",
            f"# HIP-event averages of this run: k_update {(ms[1] + ms[2]) / max(cnt[1] + cnt[2], 1):.4f} ms per launch (the stamps add two scalar memory operations per wave)"]
-    occs = []
+    occs, recs = [], []
     for launch in range(1, 7):
         rec = buf[(launch & 15) * waves * 4:((launch & 15) + 1) * waves * 4].reshape(waves, 4)
+        recs.append(rec[rec[:, 0] != 0])
         out.append(f"launch {launch} ({'black' if launch % 2 else 'red'}, iteration {(launch - 1) // 2}):")
         occ, span = analyse(rec, wpb, out)
         occs.append((occ, span))
     out.append(f"# mean slot occupancy over the six launches {100 * np.mean([o for o, _ in occs]):.2f} %, mean span {np.mean([s for _, s in occs]):.3f} ms")
+    # the six passes as one piece of work (what counts when they are chained into one launch: MPMVS_CHAIN, k_update)
+    allr = np.concatenate(recs)
+    st, en = allr[:, 0].astype(np.int64), allr[:, 1].astype(np.int64)
+    span = float(en.max() - st.min())
+    busy = float((en - st).sum())
+    firsts = [int(r[:, 0].astype(np.int64).min()) for r in recs]
+    lasts = [int(r[:, 1].astype(np.int64).max()) for r in recs]
+    overlap = [max(0, lasts[i] - firsts[i + 1]) * TICK_NS / 1e3 for i in range(5)]
+    out.append(f"# all six passes together: first wave start -> last wave end {span * TICK_NS / 1e6:.3f} ms = {span * TICK_NS / 6e6:.3f} ms per pass, slot occupancy {100 * busy / (span * 2048):.2f} % of 2048 slots; "
+               f"pass p + 1 starts before pass p ends by {', '.join(f'{o:.0f}' for o in overlap)} us")
     text = "\n".join(out)
     print(text)
     if args.out:
