@@ -990,17 +990,16 @@ static dim3 checker_grid(const mpmvs_ctx* c, const LaunchArgs& a) {
 template <bool GEOM, bool PRIOR, bool U8, int SCALE>
 static void launch_update3(mpmvs_ctx* c, const LaunchArgs& a, const ChainArgs& ch0) {
     constexpr int NT = kUpdThreads<U8, SCALE>, BW = kChkBlockW<U8, NT>, BH = kChkBlockH<U8, NT>;
+    const int V = c->hP.V;
     const int rows = c->H < a.ylimit ? c->H : a.ylimit;
     ChainArgs ch = ch0;
     ch.nbx = (c->W + BW - 1) / BW;
     ch.nby = (rows + BH - 1) / BH;
     ch.nb = ch.nbx * ch.nby;
     ch.sync = c->d_sync;
-    // every pass deals a multiple of 8 positions (chain_block): the blocks of all passes in one grid, pass-major
-    const dim3 grid((unsigned)(ch.n_pass * ((ch.nb + 7) & ~7)));
+    const dim3 grid((unsigned)(ch.n_pass * ch.nb));   // one block per work item (pass, position), handed out by ticket (k_update)
     const size_t lds = update_lds_bytes<NT>();
     const dim3 blk(NT);
-    const int V = c->hP.V;
     if (V <= 8)
         hipLaunchKernelGGL((k_update<GEOM, PRIOR, 8, U8, SCALE>), grid, blk, lds, c->stream, c->dP, c->S, a, ch);
     else if (V <= 16)

@@ -840,28 +840,31 @@ PM_DEV void update_body(const ProblemDev& P, const StateDev& S, const LaunchArgs
 // Launched one pass at a time, every pass ends in a tail: once its last block has started, wave slots run empty while the
 // slowest blocks finish -- 7.5-9 % of the slot-time of a 1600x1200 launch (profiles/r05_wave_timeline.txt; a wave lives ~300 us,
 // 1/8 of the launch).  But a block of pass p + 1 needs only the blocks of pass p within the reach of the candidate search (23 px,
-// kDirs): here the grid holds the blocks of ALL passes, each block takes a ticket (pass-major), waits until the blocks around it
-// have completed the pass before, and runs; the tail of pass p fills with the head of pass p + 1, and only the last pass of the
-// launch has a tail.  Correctness does not depend on placement or dispatch order:
-//   * tickets: a block that holds ticket t knows that every ticket < t is held by a block that has started, so whatever it
-//     waits for is running or done -- no deadlock however the hardware orders the blocks (and every wait is bounded: after
-//     kSpinLimit polls a block raises the launch's error word, which ends all waits; the host reports -101);
+// kDirs).  Here the grid holds one block per work item (pass, position) of ALL passes; a block takes a ticket -- items are numbered
+// pass-major, positions in raster order --, waits until the positions around its own have completed the pass before, runs the
+// update and signals.  The tail of pass p fills with the head of pass p + 1; only the last pass of the launch has one.
+// Correctness does not depend on placement or dispatch order:
+//   * tickets: a block that holds ticket t knows that every ticket < t is held by a block that has STARTED, so whatever it waits
+//     for is running or done -- no deadlock however the hardware orders the blocks, also not between two such launches sharing
+//     the GPU (each waits only for its own started blocks).  Every wait is bounded all the same: after kSpinLimit polls a block
+//     raises the launch's error word, which ends all waits, and the host reports -101;
 //   * hand-over (MI355X_MICROARCH.md, "inter-workgroup visibility"): results leave through write-through stores (sc0 sc1); each
-//     wave waits for its stores (s_waitcnt vmcnt(0)) and then adds 1 to its block's completion counter (agent-scope atomic);
-//     the consumer polls the counters of the blocks in reach with relaxed sc1 loads, then ONE agent-scope acquire
+//     wave waits for its stores (s_waitcnt vmcnt(0)) and then adds 1 to its position's completion counter (agent-scope atomic);
+//     the consumer polls the counters of the positions in reach with relaxed sc1 loads, then ONE agent-scope acquire
 //     (invalidates the CU's L1), waits for it, and a workgroup barrier stands between that and every load of the block;
-//   * read-after-write and write-after-read are the same condition: block B of pass p + 1 overwrites pixels of its colour that
-//     the blocks of pass p around it read (as candidates) until they END -- B waits for exactly those blocks.
-// Order: each XCD works through one horizontal band of the image (xcd_remap: L2 locality), EVEN bands top-down and ODD bands
-// bottom-up, every pass alike.  Neighbouring bands then reach their common border at about the same time -- both early or both
-// late in the pass -- so that the first blocks of the next pass find the blocks across the border done.  (Top-down everywhere,
-// the first blocks of a band would wait for the LAST blocks of the band above: no overlap at all.)
-// The sync words live in global memory: [0] ticket, [1] waves finished, [2] error, [16 + b] waves of block b that have completed
-// (monotonic over the passes).  The last wave to finish zeroes them for the next launch.
+//   * read-after-write and write-after-read are the same condition: the item (p + 1, B) overwrites pixels of its colour that the
+//     items (p, around B) read (as candidates) until they END -- it waits for exactly those.
+// Order: plain raster order, every pass alike, so what a block waits for was handed out a whole pass earlier: blocks wait 1.5 us
+// on average.  (The XCD bands of the single-pass launches -- xcd_remap -- cost 2 % here, 2.47 against 2.42 ms per pass: with a
+// band bound to an XCD the slowest band paces the round-robin dispatch, and the L2 locality the bands bought in round 1 no longer
+// shows since the view-major order of round 2.  Persistent blocks that loop over tickets fill 99 % of the wave slots instead of
+// 96 % and are no faster, 2.46 ms with the registers the loop costs: the last slots add contention, not throughput.)
+// The sync words live in global memory: [0] ticket, [1] waves that have left the kernel, [2] error, [16 + b] waves that have
+// completed position b (monotonic over the passes).  The last wave to leave zeroes them for the next launch.
 // ---------------------------------------------------------------------------
 struct ChainArgs {
     int n_pass;    // passes in this launch; pass k has colour (a.parity + k) & 1, launch id a.launch + k, iteration a.iter + (a.parity + k) / 2
-    int nb;        // blocks per pass, nbx per row of blocks, nby rows
+    int nb;        // block positions per pass, nbx per row, nby rows
     int nbx, nby;
     float thr[8];  // view-selection threshold (ref .cu:832) of the iterations a.iter, a.iter + 1, ...
     int* sync;
@@ -870,22 +873,12 @@ constexpr int kChainMaxIters = 8;
 constexpr int kSyncHeader = 16;
 constexpr int kSpinLimit = 1 << 20;   // polls of ~1-2 us each: seconds, three orders of magnitude above any legitimate wait
 
-// position v of the pass-major order -> raster block (or -1: padding, the order is padded to a multiple of 8 so that every
-// pass deals its blocks to the XCDs alike).  v & 7 = the XCD under round-robin placement; band j is reversed for odd j.
-PM_DEV int chain_block(int v, int nb) {
-    const int q = nb >> 3, r = nb & 7, j = v & 7, k = v >> 3;
-    const int len = q + (j < r ? 1 : 0);
-    if (k >= len) return -1;
-    const int start = j < r ? j * (q + 1) : r * (q + 1) + (j - r) * q;
-    return (j & 1) ? start + len - 1 - k : start + k;
-}
-
 template <bool GEOM, bool PRIOR, int MAXV, bool U8, int SCALE>
 __global__ __launch_bounds__((kUpdThreads<U8, SCALE>), kWavesPerSimd<U8>) void k_update(const ProblemDev* __restrict__ Pp, StateDev S, LaunchArgs a, ChainArgs ch) {
     const ProblemDev& P = *Pp;
     constexpr int NT = kUpdThreads<U8, SCALE>, BW = kChkBlockW<U8, NT>, BH = kChkBlockH<U8, NT>, kWaves = NT / 64;
     static_assert(NT % 64 == 0 && NT >= 64 && NT <= 256, "update blocks are 1 .. 4 waves");
-    constexpr int RX = (23 + BW - 1) / BW, RY = (23 + BH - 1) / BH, NN = (2 * RX + 1) * (2 * RY + 1);  // blocks within the 23 px of kDirs
+    constexpr int RX = (23 + BW - 1) / BW, RY = (23 + BH - 1) / BH, NN = (2 * RX + 1) * (2 * RY + 1);  // positions within the 23 px of kDirs
     static_assert(NN <= 64, "one lane polls one neighbour");
 #ifdef PM_DBG_WAVETIME
     WaveTimer wave_timer;
@@ -896,10 +889,9 @@ __global__ __launch_bounds__((kUpdThreads<U8, SCALE>), kWavesPerSimd<U8>) void k
         int t = 0;
         if (threadIdx.x == 0) t = __hip_atomic_fetch_add(&ch.sync[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         t = __builtin_amdgcn_readfirstlane(t);
-        const int n8 = (ch.nb + 7) & ~7;
-        const int pass = t / n8;
-        const int b = chain_block(t - pass * n8, ch.nb);
-        if (b >= 0 && pass > 0) {
+        const int pass = t / ch.nb;
+        const int b = t - pass * ch.nb;
+        if (pass > 0) {
             const int by = b / ch.nbx, bx = b - by * ch.nbx;
             int nbid = -1;
             if ((int)threadIdx.x < NN) {
@@ -934,7 +926,7 @@ __global__ __launch_bounds__((kUpdThreads<U8, SCALE>), kWavesPerSimd<U8>) void k
 #ifdef PM_DBG_WAVETIME
     wave_timer.ready();
 #endif
-    if (b >= 0) {
+    {
         const int k = a.parity + pass;
         update_body<GEOM, PRIOR, MAXV, U8, SCALE>(P, S, a, b, k & 1, a.launch + (uint32_t)pass, ch.thr[(k >> 1) < kChainMaxIters ? (k >> 1) : 0]);
     }
@@ -945,7 +937,7 @@ __global__ __launch_bounds__((kUpdThreads<U8, SCALE>), kWavesPerSimd<U8>) void k
 #endif
     int fin = 0;
     if ((threadIdx.x & 63) == 0) {
-        if (b >= 0) __hip_atomic_fetch_add(&ch.sync[kSyncHeader + b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&ch.sync[kSyncHeader + b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         fin = __hip_atomic_fetch_add(&ch.sync[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     fin = __builtin_amdgcn_readfirstlane(fin);
