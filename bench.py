@@ -152,11 +152,17 @@ def profile_counters(upd_avg_ms):
         elif kern == "k_update" and "avg=" in t:
             vals[t.split()[0]] = float(t.split("avg=")[1])
     src = f"profiles/{name}"
+    # since round 5 one k_update dispatch chains the passes of a scale (6 in cfg 1): the profile's per-dispatch figures are
+    # brought to ONE PASS, the unit `roofline` is quoted in (a pass = what rounds 1-4 launched as one kernel)
+    passes = float(meta.get("k_update_passes_per_dispatch", "1"))
+    if trace_avg is not None:
+        trace_avg /= passes
+    vals = {k: v / passes for k, v in vals.items()}
     if meta.get("kernel_build_sha256") != kernel_build_sha256():
         return dict(none, source=src, reason=f"{src} was collected on another kernel build (library hash {meta.get('kernel_build_sha256')} != {kernel_build_sha256()})")
     if trace_avg is None or abs(trace_avg - upd_avg_ms) > 0.03 * upd_avg_ms:
         return dict(none, source=src, reason=f"{src}: k_update averaged {trace_avg} ms there, {upd_avg_ms:.4f} ms in this run (more than 3 % apart)")
-    out = dict(none, source=src + f" (git {meta.get('git_head', '?')}, k_update trace average {trace_avg} ms; command: {meta.get('command', '?')})")
+    out = dict(none, source=src + f" (git {meta.get('git_head', '?')}, k_update trace average {trace_avg:.4f} ms per pass, {passes:g} passes per dispatch; command: {meta.get('command', '?')})")
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         out["traffic"] = (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
         out["traffic_if_fetch_doubled"] = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
@@ -797,6 +803,9 @@ def main():
                 "traffic_null_reason": prof["reason"],
                 "avg_launch_ms": round(upd_avg_ms, 4),
                 "launches_timed": upd_n,
+                "launch_is": "one PASS (BlackPixelUpdate or RedPixelUpdate over the image) -- what the reference launches as one kernel (ref .cu:1211-1236) and rounds 1-4 did too; since round 5 one "
+                             "k_update dispatch chains the passes of a window scale (6 here), its blocks waiting for their neighbours of the pass before: avg_launch_ms = HIP-event time of "
+                             "the dispatch / its passes, and every per-launch figure of this object (flop, bytes, traffic) is per pass",
                 "algorithmic_flop_per_launch": flops_per_launch,
                 "hbm": {"achieved": round(gbps, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 5),
                         "algorithmic_bytes_per_launch": hbm_bytes_per_launch},

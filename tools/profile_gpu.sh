@@ -15,6 +15,8 @@ cd ${GRAFT_REPO_ROOT:?}
 export OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 echo "python3 $*" > $OUT/command.txt
+# passes (black / red) that one k_update dispatch of this command chains (round 5): cfg 1 = 2 x 3 iterations at one scale
+echo "${PASSES_PER_DISPATCH:-6}" > $OUT/passes_per_dispatch.txt
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:?}
 python3 "$@" > $OUT/plain.json 2>/dev/null   # also fills the scene cache
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 "$@" > $OUT/traced.json 2> $OUT/trace.err

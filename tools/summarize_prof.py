@@ -17,7 +17,8 @@ try:
     print(f"# kernel_build_sha256: {bench.kernel_build_sha256()}")
 except Exception as e:  # noqa: BLE001
     print(f"# kernel_build_sha256: unavailable ({e})")
-for key, path in (("command", os.path.join(out, "command.txt")), ("git_head", os.path.join(ROOT, "build", "git_head.txt"))):
+for key, path in (("command", os.path.join(out, "command.txt")), ("git_head", os.path.join(ROOT, "build", "git_head.txt")),
+                  ("k_update_passes_per_dispatch", os.path.join(out, "passes_per_dispatch.txt"))):
     if os.path.exists(path):
         print(f"# {key}: {open(path).read().strip()}")
 
