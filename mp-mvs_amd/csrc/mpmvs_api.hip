@@ -258,7 +258,7 @@ static void free_views(mpmvs_ctx* c) {
     if (c->S.sel) (void)pool_free(c->S.sel);
     if (c->S.geom) (void)pool_free(c->S.geom);
     if (c->S.depth) (void)pool_free(c->S.depth);
-    if (c->d_sync) (void)hipFree(c->d_sync);
+    if (c->d_sync) (void)pool_free(c->d_sync);
     c->d_sync = nullptr;
 #ifdef PM_DBG_WAVETIME
     if (c->S.wavetime) (void)hipFree(c->S.wavetime);
@@ -562,7 +562,7 @@ mpmvs_ctx* mpmvs_create(int device) {
     mpmvs_ctx* c = new mpmvs_ctx();
     c->device = device;
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipMalloc(&c->dP, sizeof(ProblemDev))) != hipSuccess) {
+        (e = pool_malloc(&c->dP, sizeof(ProblemDev))) != hipSuccess) {
         g_create_err = std::string("context setup: ") + hipGetErrorString(e);
         if (c->stream) (void)hipStreamDestroy(c->stream);
         (void)hipGetLastError();
@@ -570,7 +570,8 @@ mpmvs_ctx* mpmvs_create(int device) {
         return nullptr;
     }
     std::memset(&c->hP, 0, sizeof(ProblemDev));
-    if (hipHostMalloc(&c->h_sync_err, sizeof(int), hipHostMallocDefault) == hipSuccess) *c->h_sync_err = 0; else c->h_sync_err = nullptr;
+    c->h_sync_err = static_cast<int*>(mpmvs_alloc_pinned(sizeof(int)));   // pooled page-locked memory (include/mpmvs.h)
+    if (c->h_sync_err) *c->h_sync_err = 0;
     if (const char* e = std::getenv("MPMVS_CHAIN")) c->chain = std::atoi(e) != 0;   // 0: one update launch per pass (measurements, bisecting)
     return c;
 }
@@ -582,13 +583,13 @@ void mpmvs_destroy(mpmvs_ctx* c) {
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);  // a pipelined Run() nobody waited for
     free_views(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
-    if (c->dP) (void)hipFree(c->dP);
+    if (c->dP) (void)pool_free(c->dP);   // (hipFree would synchronise the whole device)
     if (c->costs_final) (void)hipEventDestroy(c->costs_final);
     if (c->staged) (void)hipEventDestroy(c->staged);
     if (c->staging_free) (void)hipEventDestroy(c->staging_free);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->h_sync_err) (void)hipHostFree(c->h_sync_err);
+    if (c->h_sync_err) mpmvs_free_pinned(c->h_sync_err);
     delete c;
 }
 
@@ -772,7 +773,7 @@ static int set_views_impl(mpmvs_ctx* c, int n, const mpmvs_camera* cams, const f
         // chained launch leaves them zeroed again
         c->sync_blocks = ((c->W + 15) / 16 + 1) * ((c->H + 7) / 8 + 4);
         const size_t bytes = (size_t)(kSyncHeader + c->sync_blocks) * sizeof(int);
-        if (hipMalloc(&c->d_sync, bytes) != hipSuccess || hipMemsetAsync(c->d_sync, 0, bytes, c->stream) != hipSuccess) rc = -100;
+        if (pool_malloc(&c->d_sync, bytes) != hipSuccess || hipMemsetAsync(c->d_sync, 0, bytes, c->stream) != hipSuccess) rc = -100;
     }
 #ifdef PM_DBG_WAVETIME
     // room for 16 launches of one wave per 64 pixels of a colour, 4 x u64 each (generous: blocks overhang the image border)

@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/mpmvs.h"
@@ -81,13 +82,49 @@ struct Triangle {
 // that writes `data` directly after sealing should reset the stamp; as a safety net a sealed image also carries a fingerprint
 // of its contents (Fingerprint(): 4096 strided samples + the size), and an upload is only skipped while StillSealed() finds the
 // fingerprint unchanged -- a writer that forgot the stamp is then merely slower, not wrong (unless it changed none of the samples).
+// std::allocator whose value-less construct() default-initialises: a vector<float, ...>(n) or resize(n) then allocates without the
+// serial zero fill (and its page faults) of 30 MB maps that are written in full right afterwards, mostly by a parallel loop
+// Large blocks (>= 1 MB: the 7.7 / 23 / 31 MB maps of a Problem) come from a per-size free list instead of mmap / munmap: handing
+// 170 MB of maps back to the kernel cost a ProcessProblem schedule 11 ms, and as much again in page faults when the next Problem
+// mapped them afresh (round 5).  At most MPMVS_HOST_POOL_MB (default 1024) stay cached.
+void* PooledAllocate(size_t bytes);
+void PooledRelease(void* p, size_t bytes) noexcept;
+template <class T>
+struct DefaultInitAllocator : std::allocator<T> {
+    template <class U>
+    struct rebind {
+        using other = DefaultInitAllocator<U>;
+    };
+    DefaultInitAllocator() = default;
+    template <class U>
+    DefaultInitAllocator(const DefaultInitAllocator<U>&) {}
+    T* allocate(size_t n) { return static_cast<T*>(PooledAllocate(n * sizeof(T))); }
+    void deallocate(T* p, size_t n) noexcept { PooledRelease(p, n * sizeof(T)); }
+    template <class U>
+    void construct(U* p) {
+        ::new (static_cast<void*>(p)) U;
+    }
+    template <class U, class... Args>
+    void construct(U* p, Args&&... args) {
+        ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...);
+    }
+};
 struct Image {
     int rows = 0, cols = 0, ch = 1;
     uint64_t stamp = 0;
     uint64_t sealed_fingerprint = 0;
-    std::vector<float> data;
+    std::vector<float, DefaultInitAllocator<float>> data;
     Image() {}
     Image(int r, int c, int channels = 1, float v = 0.0f) : rows(r), cols(c), ch(channels), data((size_t)r * c * channels, v) {}
+    // the same shape with UNINITIALISED contents: for maps whose every element is written before it is read
+    static Image Uninitialized(int r, int c, int channels = 1) {
+        Image im;
+        im.rows = r;
+        im.cols = c;
+        im.ch = channels;
+        im.data.resize((size_t)r * c * channels);
+        return im;
+    }
     bool empty() const { return data.empty(); }
     float& at(int r, int c, int k = 0) {
         stamp = 0;

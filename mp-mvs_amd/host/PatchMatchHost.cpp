@@ -76,6 +76,54 @@ static size_t ctx_cache_cap() {
     }();
     return cap;
 }
+// the free lists behind DefaultInitAllocator (PatchMatch.h): exact-size LIFO lists of blocks of at least 1 MB
+namespace {
+struct BigBlockPool {
+    std::mutex mu;
+    std::unordered_map<size_t, std::vector<void*>> free_lists;
+    size_t cached = 0;
+    const size_t cap = [] {
+        const char* e = std::getenv("MPMVS_HOST_POOL_MB");
+        return (size_t)(e ? std::strtoull(e, nullptr, 10) : 1024ull) << 20;
+    }();
+};
+BigBlockPool& big_pool() {
+    static BigBlockPool& p = *new BigBlockPool;   // leaked on purpose: images may be destroyed after static destructors have run
+    return p;
+}
+constexpr size_t kBigBlock = 1u << 20;
+}  // namespace
+void* PooledAllocate(size_t bytes) {
+    if (bytes >= kBigBlock) {
+        BigBlockPool& P = big_pool();
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto it = P.free_lists.find(bytes);
+        if (it != P.free_lists.end() && !it->second.empty()) {
+            void* p = it->second.back();
+            it->second.pop_back();
+            P.cached -= bytes;
+            return p;
+        }
+    }
+    return ::operator new(bytes);
+}
+void PooledRelease(void* p, size_t bytes) noexcept {
+    if (!p) return;
+    if (bytes >= kBigBlock) {
+        BigBlockPool& P = big_pool();
+        std::lock_guard<std::mutex> lk(P.mu);
+        if (P.cached + bytes <= P.cap) {
+            try {
+                P.free_lists[bytes].push_back(p);
+                P.cached += bytes;
+                return;
+            } catch (...) {
+            }
+        }
+    }
+    ::operator delete(p);
+}
+
 uint64_t NewImageStamp() {
     static std::atomic<uint64_t> next(1);
     return next.fetch_add(1);
@@ -531,7 +579,7 @@ void ProcessProblem(std::vector<Scene>& Scenes, const int ID, bool geom_consiste
     }
     auto sized = [&](Image& img, int channels) {
         if (img.rows != height || img.cols != width || img.ch != channels || img.data.size() != (size_t)height * width * channels)
-            img = Image(height, width, channels);
+            img = Image::Uninitialized(height, width, channels);   // every element is written by the parallel loop below (first touch there)
     };
     sized(out.depth, 1);
     sized(out.normal, 3);
@@ -668,6 +716,7 @@ int mpmvs_host_resize_linear(const float* src, int w, int h, float* dst, int new
 int mpmvs_host_run_pipeline(int device, int n, const mpmvs_camera* cams, const float* const* images, int max_scale,
                             int geom_iterations, int planar_prior, int geomPlanarPrior, uint64_t seed,
                             const float* const* src_depths, float* out_depth, float* out_normal3, float* out_cost, int max_image_size) {
+    StageTimer tm;
     std::vector<Scene> Scenes(n);
 #pragma omp parallel for num_threads(mpmvs_host::OmpThreads()) schedule(dynamic, 1)
     for (int i = 0; i < n; ++i) {
@@ -675,26 +724,36 @@ int mpmvs_host_run_pipeline(int device, int n, const mpmvs_camera* cams, const f
         s.refID = i;
         s.cam = cams[i];
         if (max_image_size > 0) s.max_image_size = max_image_size;
-        s.image = Image(cams[i].height, cams[i].width, 1);
+        s.image = Image::Uninitialized(cams[i].height, cams[i].width, 1);
         std::memcpy(s.image.data.data(), images[i], s.image.data.size() * sizeof(float));
         if (i > 0 && src_depths) {
-            s.depth = Image(cams[i].height, cams[i].width, 1);
+            s.depth = Image::Uninitialized(cams[i].height, cams[i].width, 1);
             std::memcpy(s.depth.data.data(), src_depths[i - 1], s.depth.data.size() * sizeof(float));
             s.depth.Seal();  // held fixed over the passes: uploaded once
         }
     }
     Scenes[0].estimate = true;
     for (int i = 0; i < n; ++i) Scenes[0].srcID.push_back(i);
+    tm.lap("pipeline: scenes from arrays");
     bool pp = !geomPlanarPrior && planar_prior;  // reference src/main.cpp:20
     ProcessProblem(Scenes, 0, false, pp, seed, device, max_scale);
     for (int g = 0; g < geom_iterations; ++g) {
         pp = (geomPlanarPrior && g != geom_iterations - 1);  // reference src/main.cpp:31-34
         ProcessProblem(Scenes, 0, true, pp, seed + 1 + (uint64_t)g, device, max_scale);
     }
+    tm.lap("pipeline: passes (above)");
     const Scene& r = Scenes[0];
-    std::memcpy(out_depth, r.depth.data.data(), r.depth.data.size() * sizeof(float));
-    std::memcpy(out_normal3, r.normal.data.data(), r.normal.data.size() * sizeof(float));
-    std::memcpy(out_cost, r.cost.data.data(), r.cost.data.size() * sizeof(float));
+    const int rows = r.depth.rows;
+    const size_t row1 = (size_t)r.depth.cols, row3 = 3 * row1;
+#pragma omp parallel for num_threads(mpmvs_host::OmpThreads()) schedule(static)
+    for (int y = 0; y < rows; ++y) {   // 38 MB into the caller's (usually untouched) arrays: first touch on many threads
+        std::memcpy(out_depth + y * row1, r.depth.data.data() + y * row1, row1 * sizeof(float));
+        std::memcpy(out_normal3 + y * row3, r.normal.data.data() + y * row3, row3 * sizeof(float));
+        std::memcpy(out_cost + y * row1, r.cost.data.data() + y * row1, row1 * sizeof(float));
+    }
+    tm.lap("pipeline: copy out");
+    Scenes.clear();
+    tm.lap("pipeline: release scenes");
     return 0;
 }
 }  // extern "C"

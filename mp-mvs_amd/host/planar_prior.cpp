@@ -169,21 +169,30 @@ typedef __int128 i128;
 static std::atomic<bool> g_pool_forked(false);
 
 class HostPool {
+    // One parallel sweep: its own object, shared with the workers by reference count, so that a worker that wakes late (descheduled
+    // by another tenant of the host) finds an exhausted sweep and leaves -- it never meets the next sweep's parameters half-way and
+    // the caller never waits for a thread that has nothing left to do.  (Until round 5 every worker had to check in and out of
+    // every sweep: one worker scheduled a millisecond late cost every one of the ~20 level sweeps of a triangulation that
+    // millisecond, 8 -> 23 ms from one call to the next on a shared host.)
+    struct Sweep {
+        std::function<void(int)> job;
+        int ntasks = 0;
+        std::atomic<int> next{0}, done{0};
+    };
     std::vector<std::thread> workers;
     std::mutex mu;
     std::condition_variable wake;
-    std::function<void(int)> job;
-    std::atomic<int> next{0}, running{0};
-    int ntasks = 0;
-    unsigned long generation = 0;
+    std::shared_ptr<Sweep> current;          // guarded by mu
+    std::atomic<unsigned long> generation{0};
     bool quit = false;
     std::mutex busy;
 
-    void claim_and_run() {
+    static void take_part(Sweep& sw) {
         for (;;) {
-            const int i = next.fetch_add(1, std::memory_order_relaxed);
-            if (i >= ntasks) return;
-            job(i);
+            const int i = sw.next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= sw.ntasks) return;
+            sw.job(i);
+            sw.done.fetch_add(1, std::memory_order_release);
         }
     }
     void worker(int slot, std::vector<int> cpus) {
@@ -195,23 +204,32 @@ class HostPool {
         }
         unsigned long seen = 0;
         for (;;) {
+            // the sweeps of one triangulation follow each other within microseconds: look for the next one for a moment before going
+            // to sleep (a futex wake-up per worker and sweep otherwise)
+            for (int spin = 0; spin < 4000 && generation.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
+            std::shared_ptr<Sweep> sw;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                wake.wait(lk, [&] { return quit || generation != seen; });
+                wake.wait(lk, [&] { return quit || generation.load(std::memory_order_relaxed) != seen; });
                 if (quit) return;
-                seen = generation;
+                seen = generation.load(std::memory_order_relaxed);
+                sw = current;
             }
-            claim_and_run();
-            running.fetch_sub(1, std::memory_order_release);  // this worker has left the sweep
+            if (sw) take_part(*sw);
         }
     }
 
    public:
     explicit HostPool(int threads) {
+        // Pinning is opt-in since round 5 (MPMVS_HOST_PIN=1): the workers live as long as the process, so the scheduler has all the
+        // time it needs to spread them, and a worker pinned to a CPU that another tenant of the host keeps busy cannot get away
+        // from it.  (Round 2 pinned because its threads were created per call and stayed on their creator's CPU for longer than
+        // the triangulation took.)
         std::vector<int> cpus;
+        const char* pin = std::getenv("MPMVS_HOST_PIN");
         cpu_set_t set;
         CPU_ZERO(&set);
-        if (sched_getaffinity(0, sizeof(set), &set) == 0)
+        if (pin && std::atoi(pin) != 0 && sched_getaffinity(0, sizeof(set), &set) == 0)
             for (int i = 0; i < CPU_SETSIZE; ++i)
                 if (CPU_ISSET(i, &set)) cpus.push_back(i);
         // slot 0 is the caller's place: the workers take the CPUs after it, spread over the mask (SMT siblings are usually
@@ -236,26 +254,25 @@ class HostPool {
     int size() const { return (int)workers.size() + 1; }
     bool try_acquire() { return busy.try_lock(); }
     void release() { busy.unlock(); }
-    // fn(i) for i in [0, n) on the workers and the caller; returns when all are done.  Only between try_acquire / release.
+    // fn(i) for i in [0, n) on the workers and the caller; returns when every TASK is done (workers that are still on their way to
+    // the sweep find it exhausted).  Only between try_acquire / release.
     void run(int n, const std::function<void(int)>& fn) {
         if (n <= 0) return;
         if (n == 1 || workers.empty()) {
             for (int i = 0; i < n; ++i) fn(i);
             return;
         }
+        auto sw = std::make_shared<Sweep>();
+        sw->job = fn;
+        sw->ntasks = n;
         {
             std::lock_guard<std::mutex> lk(mu);
-            job = fn;
-            ntasks = n;
-            next.store(0, std::memory_order_relaxed);
-            running.store((int)workers.size(), std::memory_order_relaxed);
-            ++generation;
+            current = sw;
+            generation.fetch_add(1, std::memory_order_release);
         }
         wake.notify_all();
-        claim_and_run();
-        // every worker takes part in every sweep and reports when it has left it: when this returns no thread is still looking
-        // at this sweep's job or counters (a worker that wakes late must not meet the next sweep's parameters half-way)
-        while (running.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+        take_part(*sw);
+        while (sw->done.load(std::memory_order_acquire) < n) std::this_thread::yield();
     }
 };
 

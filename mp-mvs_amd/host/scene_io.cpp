@@ -43,7 +43,7 @@ static bool read_dmb(const std::string& path, Image& img, int channels) {
         fclose(f);
         return false;
     }
-    img = Image(h, w, channels);
+    img = Image::Uninitialized(h, w, channels);   // filled by the read below
     ok = fread(img.data.data(), sizeof(float), (size_t)h * w * nb, f) == (size_t)h * w * nb;
     fclose(f);
     return ok;
@@ -251,7 +251,7 @@ static bool read_image8(const std::string& path, int channels, Image8& img) {
 bool readGrayImage(const std::string& path, Image& img) {
     Image8 g;
     if (!read_image8(path, 1, g)) return false;
-    img = Image(g.rows, g.cols, 1);
+    img = Image::Uninitialized(g.rows, g.cols, 1);
     for (size_t i = 0; i < g.data.size(); ++i) img.data[i] = (float)g.data[i];  // convertTo(CV_32FC1), reference :882
     return true;
 }

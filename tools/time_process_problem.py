@@ -19,7 +19,7 @@ import bench  # noqa: E402  (scene cache)
 cams, imgs, gt = bench.load_scene(pm, 1600, 1200, 8, True)
 rng = np.random.default_rng(7)
 src_depths = [gt * (1.0 + 0.005 * rng.standard_normal(gt.shape)).astype(np.float32) for _ in range(8)]   # stand-ins of the right size
-for rep in range(2):
+for rep in range(int(os.environ.get("REPS", "2"))):
     t0 = time.perf_counter()
     hostlib.run_pipeline(0, cams, imgs, 2, 2, True, True, 5, src_depths)
     print(f"run_pipeline wall {time.perf_counter() - t0:.3f} s", file=sys.stderr)
