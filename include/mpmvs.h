@@ -111,6 +111,13 @@ int mpmvs_set_src_depths(mpmvs_ctx* ctx, int n_src, const float* const* depths, 
  * used by the multi-GPU pass barrier, which all-gathers depth maps in HBM */
 int mpmvs_set_src_depths_device(mpmvs_ctx* ctx, int n_src, const float* const* d_depths, const int* widths,
                                 const int* heights);
+/* both at once, per source: d_depths[i] != NULL copies from a dense device buffer that lies on device src_devices[i] (the
+ * context's own: device-to-device; another one of the process: a peer copy; src_devices == NULL: all on the context's device);
+ * else depths[i] != NULL uploads from the host (tightly packed rows); else the map of an earlier call is kept.  What the C++ pass
+ * schedule uses to hand the depth maps of one pass to the Problems of the next without the round trip through host memory (the
+ * reference's depths.dmb files, src/PatchMatch.cpp:620-633 -> :941-948).  Either pointer array may be NULL. */
+int mpmvs_set_src_depths_mixed(mpmvs_ctx* ctx, int n_src, const float* const* depths, const float* const* d_depths,
+                               const int* src_devices, const int* widths, const int* heights);
 
 /* CudaMemInit start state for geometric-consistency passes
  * (src/PatchMatch.cpp:1073-1086): planes = (world normal, depth) float4, costs
@@ -259,6 +266,10 @@ float mpmvs_sky_kernel_ms(void);
  * Released buffers are pooled per size.  NULL on failure. */
 void* mpmvs_alloc_pinned(size_t bytes);
 void mpmvs_free_pinned(void* p);
+/* Device memory on `device` for callers that keep data in HBM between calls (the exchange slots that receive
+ * mpmvs_export_depth_device and feed mpmvs_set_src_depths_mixed); pooled per (device, size) like the contexts' own buffers. */
+void* mpmvs_device_alloc(int device, size_t bytes);
+void mpmvs_device_free(int device, void* p);
 
 /* ---- resident texture format ---------------------------------------------- */
 /* Source images whose pixels are all integers in [0, 255] (the reference's

@@ -842,9 +842,10 @@ static int depth_upload_failed(mpmvs_ctx* c) {
     return -100;
 }
 
-int mpmvs_set_src_depths(mpmvs_ctx* c, int n_src, const float* const* depths, const int* widths, const int* heights, const size_t* pitch_bytes) {
-    if (!c) return -1;
-    ENTER(c);
+// the three public forms below: per source a device buffer (on src_devices[i], default the context's device), a host array, or
+// neither (keep what an earlier call left there)
+static int set_src_depths_impl(mpmvs_ctx* c, int n_src, const float* const* depths, const size_t* pitch_bytes, const float* const* d_depths,
+                               const int* src_devices, const int* widths, const int* heights, bool null_is_error) {
     if (c->n_img < 2 || n_src != c->n_img - 1) return fail(c, -1, "n_src must equal the number of source views");
     (void)hipStreamSynchronize(c->stream);
     if ((int)c->d_depth.size() != n_src) {
@@ -853,43 +854,51 @@ int mpmvs_set_src_depths(mpmvs_ctx* c, int n_src, const float* const* depths, co
         c->have_depths = false;
     }
     for (int i = 0; i < n_src; ++i) {
-        int rc = depth_slot(c, i, widths[i], heights[i], depths[i] != nullptr);
+        const float* dev = d_depths ? d_depths[i] : nullptr;
+        const float* host = depths ? depths[i] : nullptr;
+        if (!dev && !host && null_is_error) return fail(c, -2, "bad depth map");
+        int rc = depth_slot(c, i, widths[i], heights[i], dev != nullptr || host != nullptr);
         if (rc) {
             c->have_depths = false;
             return rc;
         }
-        if (!depths[i]) continue;  // keep the map an earlier call uploaded
-        const size_t pitch = pitch_bytes ? pitch_bytes[i] : (size_t)widths[i] * 4;
+        if (!dev && !host) continue;  // keep the map an earlier call uploaded
         ViewDev& o = c->hP.views[i];
         o.dw = widths[i], o.dh = heights[i];  // depth_slot compares against these
-        if (hipMemcpy2DAsync(c->d_depth[i], (size_t)widths[i] * 4, depths[i], pitch, (size_t)widths[i] * 4, heights[i], hipMemcpyHostToDevice, c->stream) != hipSuccess)
-            return depth_upload_failed(c);
+        const size_t bytes = (size_t)widths[i] * heights[i] * 4;
+        hipError_t e;
+        if (dev) {
+            const int from = src_devices ? src_devices[i] : c->device;
+            if (from == c->device)
+                e = hipMemcpyAsync(c->d_depth[i], dev, bytes, hipMemcpyDeviceToDevice, c->stream);
+            else
+                e = hipMemcpyPeerAsync(c->d_depth[i], c->device, dev, from, bytes, c->stream);   // over xGMI between the GPUs of a node
+        } else {
+            const size_t pitch = pitch_bytes ? pitch_bytes[i] : (size_t)widths[i] * 4;
+            e = hipMemcpy2DAsync(c->d_depth[i], (size_t)widths[i] * 4, host, pitch, (size_t)widths[i] * 4, heights[i], hipMemcpyHostToDevice, c->stream);
+        }
+        if (e != hipSuccess) return depth_upload_failed(c);
     }
     return attach_depths(c, n_src, widths, heights);
+}
+
+int mpmvs_set_src_depths(mpmvs_ctx* c, int n_src, const float* const* depths, const int* widths, const int* heights, const size_t* pitch_bytes) {
+    if (!c) return -1;
+    ENTER(c);
+    return set_src_depths_impl(c, n_src, depths, pitch_bytes, nullptr, nullptr, widths, heights, false);
 }
 
 int mpmvs_set_src_depths_device(mpmvs_ctx* c, int n_src, const float* const* d_depths, const int* widths, const int* heights) {
     if (!c) return -1;
     ENTER(c);
-    if (c->n_img < 2 || n_src != c->n_img - 1) return fail(c, -1, "n_src must equal the number of source views");
-    (void)hipStreamSynchronize(c->stream);
-    if ((int)c->d_depth.size() != n_src) {
-        for (float* p : c->d_depth) (void)pool_free(p);
-        c->d_depth.assign(n_src, nullptr);
-        c->have_depths = false;
-    }
-    for (int i = 0; i < n_src; ++i) {
-        if (!d_depths[i]) return fail(c, -2, "bad depth map");
-        int rc = depth_slot(c, i, widths[i], heights[i], true);
-        if (rc) {
-            c->have_depths = false;
-            return rc;
-        }
-        c->hP.views[i].dw = widths[i], c->hP.views[i].dh = heights[i];
-        if (hipMemcpyAsync(c->d_depth[i], d_depths[i], (size_t)widths[i] * heights[i] * 4, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
-            return depth_upload_failed(c);
-    }
-    return attach_depths(c, n_src, widths, heights);
+    return set_src_depths_impl(c, n_src, nullptr, nullptr, d_depths, nullptr, widths, heights, true);
+}
+
+int mpmvs_set_src_depths_mixed(mpmvs_ctx* c, int n_src, const float* const* depths, const float* const* d_depths, const int* src_devices, const int* widths,
+                               const int* heights) {
+    if (!c) return -1;
+    ENTER(c);
+    return set_src_depths_impl(c, n_src, depths, nullptr, d_depths, src_devices, widths, heights, false);
 }
 
 int mpmvs_set_state(mpmvs_ctx* c, const void* planes4, const void* costs) {
@@ -1987,6 +1996,21 @@ int mpmvs_sky_bilateral(int device, const unsigned char* bgr, const float* mask,
     (void)pool_free(d_out);
     (void)hipStreamDestroy(st);
     return rc;
+}
+
+void* mpmvs_device_alloc(int device, size_t bytes) {
+    if (bytes == 0 || enter_device(device) != hipSuccess) return nullptr;
+    void* p = nullptr;
+    if (pool_malloc_bytes(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void mpmvs_device_free(int device, void* p) {
+    if (!p || enter_device(device) != hipSuccess) return;
+    (void)pool_free(p);
 }
 
 void* mpmvs_alloc_pinned(size_t bytes) {

@@ -190,6 +190,18 @@ struct Scene {
     Image cost;              // last estimated costs            (costs.dmb)
     int max_image_size = 3200;
     std::shared_ptr<ProblemDeviceCache> device_cache;  // see ProblemDeviceCache; dropped with the Scene or by ReleaseDeviceCaches
+    // The depth map as it lies in HBM (round 5): a dense device buffer of rows x cols floats on `device` whose contents are those of
+    // the host map with the same stamp.  A pass schedule that keeps its Problems' contexts resident (RunFolderJacobi) lets
+    // ProcessProblem export every new depth map into device_depth_next and promotes it to device_depth at the pass barrier; the
+    // Problems of the next pass that list this image as a source then copy it device to device (or GPU to GPU) instead of
+    // uploading Scene::depth from the host -- the reference's depths.dmb round trip (src/PatchMatch.cpp:620-633 -> :941-948)
+    // without leaving HBM.  ptr == nullptr (the default): the host map is uploaded as before.  The buffers belong to whoever set them.
+    struct DeviceDepth {
+        float* ptr = nullptr;
+        int device = -1;
+        uint64_t stamp = 0;
+    };
+    DeviceDepth device_depth, device_depth_next;
 };
 // gives the HBM held by cached Problem contexts back (end of a schedule)
 void ReleaseDeviceCaches(std::vector<Scene>& Scenes);
@@ -204,6 +216,7 @@ class PatchMatchCUDA {
     int num_img = 0;
     std::vector<const Image*> images;
     std::vector<const Image*> depths;  // source depth maps of the previous pass (owned by the Scenes)
+    std::vector<const Scene::DeviceDepth*> depth_slots;  // ... and where each lies in HBM, if it does (Scene::device_depth)
     std::vector<Camera> cameras;
     mpmvs_ctx* ctx = nullptr;  // replaces reference PatchMatch.h:95-117
     int device = 0;
@@ -275,6 +288,9 @@ class PatchMatchCUDA {
     // the maps with this stamp are what the device state holds now (ProcessProblem calls it with the stamp of its results):
     // the next pass over this Problem then skips the upload of its start state
     void NoteResidentState(uint64_t stamp) { resident_state_stamp = stamp; }
+    // the context's depth map (GetDepthandNormal + median filter of the last Run()) into a dense device buffer on the context's device
+    void ExportDepthDevice(float* d_out);
+    int GetDevice() const { return device; }
     void Release(std::vector<Scene>& Scenes, const int& ID);
 };
 

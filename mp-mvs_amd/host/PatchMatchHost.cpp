@@ -160,6 +160,8 @@ void ReleaseDeviceCaches(std::vector<Scene>& Scenes) {
     for (Scene& s : Scenes) s.device_cache.reset();
 }
 
+void PatchMatchCUDA::ExportDepthDevice(float* d_out) { check(mpmvs_export_depth_device(ctx, d_out), "mpmvs_export_depth_device"); }
+
 void PatchMatchCUDA::check(int rc, const char* what) {
     if (rc != 0) {
         std::cerr << what << " failed (" << rc << "): " << mpmvs_last_error(ctx) << std::endl;
@@ -223,6 +225,7 @@ void PatchMatchCUDA::PatchMatchInit(std::vector<Scene>& Scenes, const int ID) {
     ref_scene = &Scenes[ID];
     images.clear();
     depths.clear();
+    depth_slots.clear();
     cameras.clear();
     std::vector<int>& srcID = Scenes[ID].srcID;
     num_img = (int)srcID.size();
@@ -256,6 +259,7 @@ void PatchMatchCUDA::PatchMatchInit(std::vector<Scene>& Scenes, const int ID) {
                 exit(EXIT_FAILURE);
             }
             depths.push_back(&s.depth);
+            depth_slots.push_back(&s.device_depth);
         }
     }
 }
@@ -320,17 +324,29 @@ void PatchMatchCUDA::CudaMemInit(Scene& scene) {
             hs.push_back(d.rows);
         }
         // a source depth map the adopted context already holds (same sealed contents, Image::stamp) is not uploaded again:
-        // NULL keeps it (include/mpmvs.h).  The reference uploads all of them on every call (:1027-1050).
+        // NULL keeps it (include/mpmvs.h).  The reference uploads all of them on every call (:1027-1050).  A map that also lies in
+        // HBM with the same stamp (Scene::device_depth: the pass schedule exported it there) is copied from there -- device to
+        // device, or GPU to GPU when its Problem runs on another device -- instead of crossing PCIe.
         if (resident_depth_stamps.size() != depths.size()) resident_depth_stamps.assign(depths.size(), 0);
+        std::vector<const float*> dev_ptr(depths.size(), nullptr);
+        std::vector<int> dev_of(depths.size(), device);
         bool any = false;
         for (size_t i = 0; i < depths.size(); ++i) {
-            if (depths[i]->stamp != 0 && depths[i]->stamp == resident_depth_stamps[i] && depths[i]->StillSealed())
+            const Scene::DeviceDepth& slot = *depth_slots[i];
+            if (depths[i]->stamp != 0 && depths[i]->stamp == resident_depth_stamps[i] && depths[i]->StillSealed()) {
                 dptr[i] = nullptr;
-            else
+            } else if (slot.ptr && slot.stamp != 0 && slot.stamp == depths[i]->stamp && depths[i]->StillSealed()) {
+                dptr[i] = nullptr;
+                dev_ptr[i] = slot.ptr;
+                dev_of[i] = slot.device;
                 any = true;
+            } else {
+                any = true;
+            }
             resident_depth_stamps[i] = depths[i]->stamp;
         }
-        if (any) check(mpmvs_set_src_depths(ctx, num_img - 1, dptr.data(), ws.data(), hs.data(), nullptr), "mpmvs_set_src_depths");
+        if (any)
+            check(mpmvs_set_src_depths_mixed(ctx, num_img - 1, dptr.data(), dev_ptr.data(), dev_of.data(), ws.data(), hs.data()), "mpmvs_set_src_depths_mixed");
         // previous result of this image is the start state (reference :1052-1086)
         if (scene.depth.empty() || scene.normal.empty() || scene.cost.empty()) {
             std::cout << "Can not read this depth image !" << std::endl;
@@ -605,6 +621,14 @@ void ProcessProblem(std::vector<Scene>& Scenes, const int ID, bool geom_consiste
     out.normal.SealAs(stamp);
     out.cost.SealAs(stamp);
     MP.NoteResidentState(stamp);
+    // a pass schedule that hands depth maps over in HBM: this Problem's new map goes into the buffer it provided (on the device the
+    // Problem ran on), to be promoted at the pass barrier
+    if (scene.device_depth_next.ptr && scene.device_depth_next.device == MP.GetDevice()) {
+        MP.ExportDepthDevice(scene.device_depth_next.ptr);
+        scene.device_depth_next.stamp = stamp;
+    } else {
+        scene.device_depth_next.stamp = 0;
+    }
     if (!results) {
         scene.depth = std::move(out.depth);
         scene.normal = std::move(out.normal);

@@ -386,6 +386,26 @@ int RunFolderJacobi(const std::string& input_folder, int max_src, int max_image_
     // after the first two passes no pass allocates or page-faults fresh result memory
     std::vector<ProblemResult> spare(n);
     mpmvs_host::SetConcurrentCallers(nworkers);
+    // Device-side hand-over of the depth maps (round 5; MPMVS_FOLDER_HOST_EXCHANGE=1 keeps the host staging of rounds 1-4): every
+    // Problem owns two dense depth buffers on its device.  ProcessProblem exports the map of pass k into one of them while the
+    // Problems of pass k still read the maps of pass k - 1 from the other (Jacobi); the barrier swaps them, and the Problems of
+    // pass k + 1 copy their source maps out of HBM -- device to device, or GPU to GPU when the source's Problem lives on another
+    // device of `devices` (hipMemcpyPeerAsync; that branch has not run anywhere yet: the pool has one-GPU boxes only).
+    const bool device_exchange = geom_iterations > 0 && std::getenv("MPMVS_FOLDER_HOST_EXCHANGE") == nullptr;
+    std::vector<std::pair<int, float*>> exchange_buffers;   // (device, pointer): released at the end
+    if (device_exchange)
+        for (size_t k = 0; k < todo.size(); ++k) {
+            Scene& s = Scenes[todo[k]];
+            const int device = devices[k % devices.size()];
+            const size_t bytes = (size_t)s.image.rows * s.image.cols * sizeof(float);
+            for (Scene::DeviceDepth* slot : {&s.device_depth, &s.device_depth_next}) {
+                slot->ptr = static_cast<float*>(mpmvs_device_alloc(device, bytes));
+                slot->device = device;
+                slot->stamp = 0;
+                if (slot->ptr) exchange_buffers.push_back({device, slot->ptr});
+            }
+            if (!s.device_depth.ptr || !s.device_depth_next.ptr) s.device_depth.ptr = s.device_depth_next.ptr = nullptr;   // no memory: this map travels through the host
+        }
     auto run_pass = [&](bool geom, bool pp, uint64_t pass_seed) {
         std::vector<ProblemResult> results(n);
         for (int i : todo) results[i] = std::move(spare[i]);
@@ -415,11 +435,14 @@ int RunFolderJacobi(const std::string& input_folder, int max_src, int max_image_
             std::swap(Scenes[i].normal, results[i].normal);
             std::swap(Scenes[i].cost, results[i].cost);
             spare[i] = std::move(results[i]);  // the maps of the pass before: storage for the pass after the next
+            std::swap(Scenes[i].device_depth, Scenes[i].device_depth_next);   // ... and the same hand-over in HBM
         }
     };
     run_pass(false, !geomPlanarPrior && planar_prior, seed);
     for (int g = 0; g < geom_iterations; ++g) run_pass(true, geomPlanarPrior && g != geom_iterations - 1, seed + 100003ull * (g + 1));
     mpmvs_host::SetConcurrentCallers(1);
+    for (int i : todo) Scenes[i].device_depth = Scenes[i].device_depth_next = Scene::DeviceDepth();
+    for (const auto& b : exchange_buffers) mpmvs_device_free(b.first, b.second);
     if (in_memory) {
         in_memory->assign(n, ProblemResult());
         for (int i : todo) {

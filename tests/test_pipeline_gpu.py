@@ -282,6 +282,19 @@ def test_folder_jacobi_workers_equal_the_scheduler(pm, engine, tmp_path):
         out[workers] = [tuple(hostlib.read_dmb(d / "MPMVS" / f"2333_{i:08d}" / f"{k}.dmb") for k in ("depths", "normals", "costs")) for i in range(6)]
     for a, b in zip(out[3], out[1]):
         assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # the depth maps change hands in HBM between the passes (round 5: Scene::device_depth, mpmvs_set_src_depths_mixed); staged through
+    # host arrays as in rounds 1-4 (MPMVS_FOLDER_HOST_EXCHANGE=1) the files are the same, bit for bit
+    import os
+    d = tmp_path / "host_exchange"
+    hostlib.write_dataset(str(d), cams, imgs, neigh)
+    os.environ["MPMVS_FOLDER_HOST_EXCHANGE"] = "1"
+    try:
+        assert hostlib.run_folder_jacobi(d, devices=(0,), workers=3, geom_iterations=2, planar_prior=True, geom_planar_prior=True, max_scale=1, seed=321) == 6
+    finally:
+        del os.environ["MPMVS_FOLDER_HOST_EXCHANGE"]
+    for i in range(6):
+        for k, want in zip(("depths", "normals", "costs"), out[3][i]):
+            assert np.array_equal(hostlib.read_dmb(d / "MPMVS" / f"2333_{i:08d}" / f"{k}.dmb"), want), (i, k)
     file_cams = []
     for i in range(6):
         c = hostlib.read_camera(tmp_path / "w1" / "cams" / f"{i:08d}_cam.txt")

@@ -84,16 +84,26 @@ def main():
         depth, normal, cost = hostlib.run_folder_jacobi_in_memory(folder, n, H, W, devices=(0,), workers=args.workers, geom_iterations=2, planar_prior=True,
                                                                   geom_planar_prior=True, max_scale=2, seed=args.seed)
         t_folder = time.perf_counter() - t0
+        # ... and once more with the depth maps staged through host arrays between the passes (the hand-over of rounds 1-4)
+        os.environ["MPMVS_FOLDER_HOST_EXCHANGE"] = "1"
+        t0 = time.perf_counter()
+        depth_h, normal_h, cost_h = hostlib.run_folder_jacobi_in_memory(folder, n, H, W, devices=(0,), workers=args.workers, geom_iterations=2, planar_prior=True,
+                                                                        geom_planar_prior=True, max_scale=2, seed=args.seed)
+        t_folder_host = time.perf_counter() - t0
+        del os.environ["MPMVS_FOLDER_HOST_EXCHANGE"]
+        same_host = bool(np.array_equal(depth_h, depth) and np.array_equal(normal_h, normal) and np.array_equal(cost_h, cost))
+        del depth_h, normal_h, cost_h
     finally:
         shutil.rmtree(folder, ignore_errors=True)
     same = [bool(np.array_equal(res[i][0][..., 3], depth[i]) and np.array_equal(res[i][0][..., :3], normal[i]) and np.array_equal(res[i][1], cost[i])) for i in range(n)]
     acc = [float((np.abs(res[i][0][..., 3] - gts[i]) / gts[i] < 0.01).mean()) for i in range(n)]
     print(json.dumps({"workload": f"configs[4] on one MI355X: {n} Problems ({g}x{g} camera grid, 8 nearest neighbours), {W}x{H}, shipped schedule, Jacobi",
                       "problems": n, "scheduler_device_exchange_s": round(t_sched, 3), "scheduler_Mpix_per_s": round(n * W * H / t_sched / 1e6, 2),
-                      "folder_jacobi_cpp_s": round(t_folder, 3), "host_threads": args.workers, "passes": passes,
+                      "folder_jacobi_cpp_s": round(t_folder, 3), "folder_jacobi_cpp_host_exchange_s": round(t_folder_host, 3),
+                      "folder_device_exchange_equals_host_exchange": same_host, "host_threads": args.workers, "passes": passes,
                       "bit_identical_problems": int(sum(same)), "all_bit_identical": bool(all(same)),
                       "within_1pct_of_gt_mean": round(float(np.mean(acc)), 4), "render_s": round(t_render, 1)}), flush=True)
-    return 0 if all(same) else 1
+    return 0 if all(same) and same_host else 1
 
 
 if __name__ == "__main__":
