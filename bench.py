@@ -518,8 +518,11 @@ def launch_ranks(n, argv):
     def pump():
         for line in procs[0].stdout:
             lines.append(line)
-            sys.stdout.write(line)
-            sys.stdout.flush()
+            # stdout carries the JSON line only; whatever else rank 0 or its libraries print there (gloo announces its connections
+            # on stdout) goes to stderr
+            out = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+            out.write(line)
+            out.flush()
 
     th = threading.Thread(target=pump, daemon=True)
     th.start()

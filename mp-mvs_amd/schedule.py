@@ -174,10 +174,22 @@ class SceneScheduler:
             for k, i in enumerate(self.owned):
                 mine[k] = self.results[i][0][..., 3]
             if self.world > 1:
+                import time
                 import torch
                 t = torch.from_numpy(mine)
                 outs = [torch.empty_like(t) for _ in range(self.world)]
+                timed = isinstance(getattr(self, "timing", None), list)
+                if timed:
+                    ta = time.perf_counter()
+                    self.dist.barrier()
+                    tb = time.perf_counter()
                 self.dist.all_gather(outs, t)
+                if timed:
+                    tc = time.perf_counter()
+                    recv = (self.world - 1) * mine.size * 4
+                    self.last_exchange = {"wait_for_slowest_rank_ms": round((tb - ta) * 1e3, 3), "all_gather_ms": round((tc - tb) * 1e3, 3),
+                                          "bytes_sent_per_rank": mine.size * 4, "bytes_received_per_rank": recv,
+                                          "received_GB_per_s": round(recv / max(tc - tb, 1e-9) / 1e9, 2), "staged_through_host": True}
                 full = np.concatenate([o.numpy() for o in outs], 0)
             else:
                 full = mine
