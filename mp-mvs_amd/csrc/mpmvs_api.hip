@@ -1428,7 +1428,7 @@ int mpmvs_export_depth_device(mpmvs_ctx* c, float* d_out) {
 }
 
 // mapping: 0 = one thread per pixel (k_eval_ncc); the cooperative lane-group mappings 1..4 of round 2 were measured, not
-// adopted and removed again
+// adopted and removed again (profiles/EXPERIMENTS.md, 10)
 static int eval_ncc_impl(mpmvs_ctx* c, const mpmvs_params* p, const void* planes_cam4, int nh, int scale, int mapping, void* out, float* kernel_ms) {
     if (!c || !p) return -1;
     ENTER(c);

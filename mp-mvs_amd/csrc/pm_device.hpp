@@ -338,7 +338,7 @@ PM_DEV float4 perturbed_normal(const ProblemDev& P, int px, int py, const float4
 // LDS layout (one array): [18 * kBlockThreads float4][tile floats].
 // Round 2 tried 4-byte records (w only, w*r recomputed from the tile in every evaluation) so that three blocks fit a CU, both
 // for the whole update kernel (squeezed into 168 registers: slower) and for its phase A as a kernel of its own (fits easily:
-// exactly as fast as with two waves per SIMD): the third wave buys this workload nothing.
+// exactly as fast as with two waves per SIMD): the third wave buys this workload nothing (profiles/EXPERIMENTS.md, 14 and 22).
 // ---------------------------------------------------------------------------
 constexpr int kBlockThreads = 256;  // threads per block of the all-pixel NCC kernels (k_init, k_eval_ncc); the update kernel has its own (kUpdThreads)
 extern __shared__ float pm_lds[];  // dynamic LDS of the NCC kernels
