@@ -452,7 +452,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // hi both are texel hi, so the interpolated value does not depend on the fraction
 // there and clamping the coordinate itself gives the same bits -- with no apron
 // and non-negative texel indices.
+#ifdef PM_DBG_NOCLAMP   // measurement builds only (wrong at the image border): what the two clamps per tap cost
+PM_DEV float clamp_coord(float s, float hi) { return s; }
+#else
 PM_DEV float clamp_coord(float s, float hi) { return __builtin_amdgcn_fmed3f(s, 0.0f, hi); }
+#endif
 
 // floor + float->int in one instruction (hipcc only selects it under fast-math)
 PM_DEV int floor_to_int(float c) {
