@@ -496,6 +496,73 @@ def test_cfg1_mid_size_bit_exact(pm, oracle, engine):
     assert (np.abs(gpu.get()[0][..., 3] - gt) / gt < 0.01).mean() > 0.9
 
 
+def test_chained_update_launch_equals_one_launch_per_pass_under_load(pm, engine):
+    """The hand-over INSIDE the chained update launch (round 5: one launch per window scale, blocks waiting for their neighbours of
+    the pass before; write-through stores, completion counters, one acquire per block) against the same passes launched one kernel
+    at a time (MPMVS_CHAIN=0: kernel boundaries do the hand-over, as in rounds 1-4): bit for bit at 1600x1200, three window
+    scales, all three modes -- thirty times in a row while a second context keeps the GPU unevenly busy from another thread (a stale
+    line, an early flag or a missed wait would show as a difference at least once: every block hands over to blocks on other XCDs)."""
+    import os
+    import threading
+    W, H, V = 1600, 1200, 8
+    sc = pm.synth.make_problem_scene(W, H, n_src=V, quantize=True)
+    cams, imgs = sc.problem(0, list(range(1, V + 1)))
+    dmin, dmax = (float(v) for v in pm.synth.kernel_depth_range(cams[0]))
+    rng = np.random.default_rng(3)
+    depths = [sc.views[i].gt_depth * (1.0 + 0.005 * rng.standard_normal((H, W))).astype(np.float32) for i in range(1, V + 1)]
+    prior = np.zeros((H, W, 4), np.float32)
+    prior[..., 2] = -1.0
+    prior[..., 3] = sc.views[0].gt_depth
+    mask = (rng.uniform(size=(H, W)) < 0.6).astype(np.uint32)
+
+    def schedule(h, seed):
+        """photometric at three scales, a geometric Run, a prior Run: (planes, costs) after each"""
+        out = []
+        p = pm.PatchMatchParams(num_images=V + 1, depth_min=dmin, depth_max=dmax, max_scale=2)
+        h.run(p, seed)
+        out.append(h.get())
+        p.geom_consistency, p.max_iterations = True, 2
+        h.run(p, seed + 1)
+        out.append(h.get())
+        p.geom_consistency, p.planar_prior, p.max_iterations = False, True, 3
+        h.run(p, seed + 2)
+        out.append(h.get())
+        return out
+
+    os.environ["MPMVS_CHAIN"] = "0"
+    try:
+        plain = engine.create(0)
+    finally:
+        del os.environ["MPMVS_CHAIN"]
+    chained, noise = engine.create(0), engine.create(0)
+    for h in (plain, chained, noise):
+        h.set_views(cams, imgs)
+        h.set_src_depths(depths)
+        h.set_prior(prior, mask)
+    want = schedule(plain, SEED)
+    stop = threading.Event()
+
+    def load():   # a second Problem on its own stream: its chained launches share the CUs with the ones under test, in bursts
+        q = pm.PatchMatchParams(num_images=V + 1, depth_min=dmin, depth_max=dmax, max_scale=0, max_iterations=1)
+        k = 0
+        while not stop.is_set():
+            noise.run(q, 1000 + k)
+            k += 1
+            if k % 3 == 0:
+                stop.wait(0.004)
+
+    th = threading.Thread(target=load)
+    th.start()
+    try:
+        for rep in range(30):
+            got = schedule(chained, SEED)
+            for stage, (g, w_) in enumerate(zip(got, want)):
+                assert np.array_equal(g[0], w_[0]) and np.array_equal(g[1], w_[1]), f"repetition {rep}, stage {stage}: {int((g[0] != w_[0]).any(-1).sum())} pixels differ"
+    finally:
+        stop.set()
+        th.join()
+
+
 def test_cfg1_full_size_properties(pm, engine):
     """cfg 1 at its real size (1600x1200, 8 source views) through size-independent
     properties: determinism for a seed, sensitivity to the seed, value ranges,
