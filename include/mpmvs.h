@@ -155,7 +155,11 @@ int mpmvs_get_prior(mpmvs_ctx* ctx, void* prior_planes4, void* mask_u32);
  * curand_init(clock64(), ...) (src/PatchMatch.cu:546).  Blocks until done.
  * params->geom_consistency together with params->planar_prior is rejected (-7):
  * the reference never runs that combination (ProcessProblem clears
- * geom_consistency before the prior Run(), src/PatchMatch.cpp:535). */
+ * geom_consistency before the prior Run(), src/PatchMatch.cpp:535).
+ * The red/black passes of one window scale (BlackPixelUpdate / RedPixelUpdate, :1211-1236) are ONE launch whose blocks wait for
+ * their neighbours of the pass before (same launch numbering, same results; MPMVS_CHAIN=0 in the environment of mpmvs_create
+ * launches one kernel per pass).  -101: such a launch gave up waiting (a bounded wait that a correct build never exhausts);
+ * the context's results are invalid, the context itself stays usable. */
 int mpmvs_run(mpmvs_ctx* ctx, const mpmvs_params* params, uint64_t seed);
 /* Run() together with the device-to-host copies that end it in the reference (src/PatchMatch.cu:1246-1251): planes (float4 =
  * world normal + depth), costs and geometric costs into host buffers of W*H elements (each may be NULL; pinned memory makes
