@@ -24,6 +24,9 @@ _EXTRA = {
     "texture_filter_bits": (C.c_int, []),
     "set_src_depths_device": (C.c_int, [_P, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "export_depth_device": (C.c_int, [_P, _P]),
+    "set_src_depths_mixed": (C.c_int, [_P, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "device_alloc": (C.c_void_p, [C.c_int, C.c_size_t]),
+    "device_free": (None, [C.c_int, C.c_void_p]),
     "set_profiling": (C.c_int, [_P, C.c_int]),
     "set_texture_format": (C.c_int, [_P, C.c_int]),
     "texture_format": (C.c_int, [_P]),

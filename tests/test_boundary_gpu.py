@@ -224,6 +224,59 @@ def test_set_src_depths_keeps_maps_passed_as_null(pm, engine):
     assert not np.array_equal(c0.eval_geom(prm, planes)[1], ga[1])  # the changed map is really in use
 
 
+def test_set_src_depths_mixed_device_host_and_kept_maps(pm, engine):
+    """mpmvs_set_src_depths_mixed (round 5: the depth-map hand-over of the C++ pass schedule): per source a device buffer (from
+    mpmvs_device_alloc, filled by mpmvs_export_depth_device of another context), a host array, or NULL = keep -- the state a plain host
+    upload of the same maps gives (geometric-cost probe and a geometric Run(), bit for bit); NULL without a resident map is an error"""
+    _, fns = engine.load()
+    W, H = 96, 64
+    sc = pm.synth.make_problem_scene(W, H, n_src=3, spacing=0.5, quantize=True)
+    cams, imgs = sc.problem(0, [1, 2, 3])
+    dmin, dmax = pm.synth.kernel_depth_range(cams[0])
+    prm = pm.PatchMatchParams(num_images=4, depth_min=float(dmin), depth_max=float(dmax), max_scale=0)
+    # the three source depth maps: map 0 is what a context's Run() leaves behind (exported on the device), maps 1 and 2 are host arrays
+    producer = engine.create(0)
+    producer.set_views(cams, imgs)
+    producer.run(prm, 5)
+    d0 = np.ascontiguousarray(producer.get()[0][..., 3])
+    rng = np.random.default_rng(2)
+    d1, d2 = (np.ascontiguousarray(sc.views[i].gt_depth * (1.0 + 0.01 * rng.standard_normal((H, W))), np.float32) for i in (2, 3))
+    slot = fns["device_alloc"](0, W * H * 4)
+    assert slot
+    producer.export_depth_device(slot)
+    FP = C.POINTER(C.c_float)
+    ws, hs = (C.c_int * 3)(W, W, W), (C.c_int * 3)(H, H, H)
+
+    def mixed(ctx, host, dev):
+        hp = (FP * 3)(*[m.ctypes.data_as(FP) if m is not None else None for m in host])
+        dp = (C.c_void_p * 3)(*[d if d else None for d in dev])
+        return fns["set_src_depths_mixed"](ctx._ctx, 3, hp, dp, None, ws, hs)
+
+    a = engine.create(0)
+    a.set_views(cams, imgs)
+    assert mixed(a, [None, None, None], [None, None, None]) != 0          # nothing resident yet
+    assert mixed(a, [None, d1, d2], [slot, None, None]) == 0               # one from HBM, two from the host
+    assert mixed(a, [None, None, None], [None, None, None]) == 0           # ... all kept
+    assert mixed(a, [None, d1, None], [slot, None, None]) == 0             # any subset again
+    b = engine.create(0)
+    b.set_views(cams, imgs)
+    b.set_src_depths([d0, d1, d2])
+    planes = np.zeros((H, W, 4), np.float32)
+    planes[..., 2] = -1.0
+    planes[..., 3] = sc.views[0].gt_depth
+    assert np.array_equal(a.eval_geom(prm, planes), b.eval_geom(prm, planes))
+    for h in (a, b):
+        h.run(prm, 5)                                                       # a start state for the geometric Run()
+    prm.geom_consistency, prm.max_iterations = True, 2
+    for h in (a, b):
+        h.run(prm, 9)
+    assert all(np.array_equal(x, y) for x, y in zip(a.get(geom=True), b.get(geom=True)))
+    fns["device_free"](0, slot)
+    again = fns["device_alloc"](0, W * H * 4)                              # pooled per (device, size)
+    assert again == slot
+    fns["device_free"](0, again)
+
+
 def test_pinned_host_buffers_round_trip(pm, engine):
     """mpmvs_alloc_pinned / mpmvs_free_pinned: usable as the host arrays of mpmvs_run_get, pooled per size"""
     _, fns = engine.load()
