@@ -150,8 +150,11 @@ inline size_t ncc_lds_bytes(int bw, int bh, int scale) {
 constexpr int kXchgBytesPerWave = 2048;
 template <int NT>
 constexpr int kLdsXchgFloats = (NT / 64) * kXchgBytesPerWave / 4;  // = the largest LDS-resident reference tile of the update kernel (Win::tile_in_lds)
+#ifndef PM_DBG_LDS_PAD   // measurement builds: extra dynamic LDS per update block (fewer blocks per CU)
+#define PM_DBG_LDS_PAD 0
+#endif
 template <int NT>
-inline size_t update_lds_bytes() { return (size_t)(kLdsWeightFloatsOf<NT> + kLdsXchgFloats<NT>) * sizeof(float); }
+inline size_t update_lds_bytes() { return (size_t)(kLdsWeightFloatsOf<NT> + kLdsXchgFloats<NT>) * sizeof(float) + (size_t)(PM_DBG_LDS_PAD); }
 
 // ---------------------------------------------------------------------------
 // InitializeScore, ref .cu:536-573 (+ :497-534)
